@@ -1,0 +1,34 @@
+# Build of the MI355X-native Archon BWT path.
+#   make lib      -> dark-archon_amd/libarchon_hip.so   (HIP kernels + C ABI, gfx950)
+#   make cli      -> bin/archon                          (C++ host: Archon class mirror + a7 CLI)
+#   make oracle   -> oracle/liboracle.so (+ oracle/_ref/* when /root/reference is present)
+HIPCC     ?= hipcc
+CXX       ?= g++
+ARCH      ?= gfx950
+PKG        = dark-archon_amd
+CSRC       = $(PKG)/csrc
+HIPFLAGS   = -O3 --offload-arch=$(ARCH) -std=c++17 -fPIC -Wall -Wno-unused-function
+LIB        = $(PKG)/libarchon_hip.so
+
+all: lib cli oracle
+
+lib: $(LIB)
+
+$(LIB): $(CSRC)/archon_hip.hip $(wildcard $(CSRC)/*.hiph) include/archon_hip.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/archon_hip.hip
+
+cli: bin/archon
+
+bin/archon: $(PKG)/host/archon_host.cpp $(PKG)/host/archon_main.cpp $(PKG)/host/archon_host.h include/archon.h $(LIB)
+	@mkdir -p bin
+	$(CXX) -O2 -std=c++17 -Wall -Iinclude -o $@ $(PKG)/host/archon_main.cpp $(PKG)/host/archon_host.cpp \
+	    -L$(PKG) -larchon_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)'
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf bin $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib cli oracle clean

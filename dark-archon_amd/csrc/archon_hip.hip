@@ -1,0 +1,584 @@
+// archon_hip.hip -- C ABI of libarchon_hip.so (include/archon_hip.h): contexts,
+// the forward / inverse drivers and the host-buffer wrappers.  gfx950 only.
+#include "common.hiph"
+#include "util.hiph"
+#include "radix_sort.hiph"
+#include "forward.hiph"
+#include "inverse.hiph"
+
+#include <stdarg.h>
+#include <stdlib.h>
+#include <vector>
+
+namespace archon {
+
+// ------------------------------------------------------------------ errors
+static thread_local char t_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof t_err, fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------ contexts
+static constexpr int kMaxDev = 64;
+static Ctx *g_ctx[kMaxDev];
+static std::mutex g_ctx_mu;
+
+static int device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int ctx_get(int dev, Ctx **out)
+{
+    const int ndev = device_count();
+    if (ndev <= 0) {
+        set_error("no HIP device available (libarchon_hip has no CPU fallback)");
+        return ARCHON_E_NODEVICE;
+    }
+    if (dev < 0 || dev >= ndev || dev >= kMaxDev) {
+        set_error("device %d out of range (have %d)", dev, ndev);
+        return ARCHON_E_NODEVICE;
+    }
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    if (!g_ctx[dev]) {
+        Ctx *c = new Ctx();
+        c->dev = dev;
+        memset(&c->stats, 0, sizeof c->stats);
+        ARCHON_HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        ARCHON_HIP_TRY(hipHostMalloc((void **)&c->h_mail, Ctx::kMailWords * sizeof(uint32_t), hipHostMallocDefault));
+        ARCHON_HIP_TRY(hipMalloc((void **)&c->d_mail, Ctx::kMailWords * sizeof(uint32_t)));
+        g_ctx[dev] = c;
+    }
+    *out = g_ctx[dev];
+    return ARCHON_OK;
+}
+
+int ctx_ensure_arena(Ctx *c, size_t bytes)
+{
+    if (bytes <= c->arena_bytes) return ARCHON_OK;
+    ARCHON_HIP_TRY(hipDeviceSynchronize());
+    if (c->arena) {
+        ARCHON_HIP_TRY(hipFree(c->arena));
+        c->arena = nullptr;
+        c->arena_bytes = 0;
+    }
+    const size_t want = bytes + (bytes >> 4) + (1u << 20);
+    if (hipMalloc((void **)&c->arena, want) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("device arena allocation of %zu bytes failed", want);
+        return ARCHON_E_NOMEM;
+    }
+    c->arena_bytes = want;
+    return ARCHON_OK;
+}
+
+// ------------------------------------------------------------------ forward driver
+static size_t forward_arena_bytes(uint32_t n)
+{
+    const size_t N = n;
+    size_t b = 0;
+    auto add = [&](size_t bytes) { b += (bytes + 255) & ~size_t(255); };
+    add(N + 64);                    // aligned copy of x (when needed)
+    add(8 * N); add(8 * N);         // keyA keyB
+    add(4 * N); add(4 * N);         // valA valB
+    add(4 * (N + 1));               // rank
+    add(4 * N);                     // sa (when the caller wants none)
+    add(4 * N); add(4 * N); add(4 * N);       // v / gstart, keep, dst
+    for (int i = 0; i < 6; ++i) add(4 * N);   // upos, ug, uitem (double-buffered)
+    add(4 * scan_temp_words(N));
+    add(4 * rs::status_words(n));
+    add(4 * 8 * 256); add(4 * 8 * 256);       // ghist, gstart
+    add(4 * 1024);                            // counts, starts, ticket, err, base, totals
+    return b + 4096;
+}
+
+static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n, uint32_t *d_sa_user,
+                       uint8_t *d_bwt, uint32_t *d_base_out)
+{
+    ARCHON_TRY(ctx_ensure_arena(c, forward_arena_bytes(n)));
+    c->arena_reset();
+    c->launches = 0;
+    archon_hip_stats &st = c->stats;
+    memset(&st, 0, sizeof st);
+    st.n = n;
+
+    uint8_t *xa = c->alloc<uint8_t>((size_t)n + 64);
+    uint64_t *keyA = c->alloc<uint64_t>(n), *keyB = c->alloc<uint64_t>(n);
+    uint32_t *valA = c->alloc<uint32_t>(n), *valB = c->alloc<uint32_t>(n);
+    uint32_t *rank = c->alloc<uint32_t>((size_t)n + 1);
+    uint32_t *sa_own = c->alloc<uint32_t>(n);
+    uint32_t *v = c->alloc<uint32_t>(n), *keep = c->alloc<uint32_t>(n), *dst = c->alloc<uint32_t>(n);
+    uint32_t *upos[2], *ug[2], *uitem[2];
+    for (int i = 0; i < 2; ++i) {
+        upos[i] = c->alloc<uint32_t>(n);
+        ug[i] = c->alloc<uint32_t>(n);
+        uitem[i] = c->alloc<uint32_t>(n);
+    }
+    uint32_t *scan_tmp = c->alloc<uint32_t>(scan_temp_words(n));
+    rs::Scratch sc;
+    sc.d_status = c->alloc<uint32_t>(rs::status_words(n));
+    sc.d_ghist = c->alloc<uint32_t>(8 * 256);
+    sc.d_gstart = c->alloc<uint32_t>(8 * 256);
+    uint32_t *small = c->alloc<uint32_t>(1024);
+    if (!small || !sc.d_gstart || !upos[1]) {
+        set_error("arena exhausted");
+        return ARCHON_E_NOMEM;
+    }
+    uint32_t *d_counts = small, *d_starts = small + 256, *d_total = small + 600;
+    sc.d_ticket = small + 601;
+    sc.d_err = small + 602;
+    uint32_t *d_base = small + 603;
+    sc.h_mail = c->h_mail;
+    ARCHON_HIP_TRY(hipMemsetAsync(small, 0, 1024 * sizeof(uint32_t), s));
+
+    const uint8_t *d_x = d_x_in;
+    if ((uintptr_t)d_x_in & 15) {   // kernels want 16-byte aligned text
+        ARCHON_HIP_TRY(hipMemcpyAsync(xa, d_x_in, n, hipMemcpyDeviceToDevice, s));
+        d_x = xa;
+    }
+    uint32_t *sa = d_sa_user ? d_sa_user : sa_own;
+
+    StageTimer tm(s);
+    const int e0 = tm.mark();
+
+    // A2: bucket setup
+    ARCHON_TRY(launch_hist256(s, d_x, n, d_counts, n));
+    hipLaunchKernelGGL(k_scan257, dim3(1), dim3(64), 0, s, d_counts, d_starts);
+    c->launches += 2;
+    const int e1 = tm.mark();
+
+    // A4: first-stage LSB radix bucketing on 7 key bytes
+    const uint32_t g256 = div_up(n, 256);
+    hipLaunchKernelGGL(fwd::k_init_keys, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, keyA, valA);
+    ARCHON_HIP_TRY(hipGetLastError());
+    ++c->launches;
+    bool in_b = false;
+    ARCHON_TRY(rs::sort_pairs(s, sc, keyA, valA, keyB, valB, n, 0xFEu, &in_b, &st.radix_passes, &c->launches));
+    uint64_t *kS = in_b ? keyB : keyA, *kT = in_b ? keyA : keyB;
+    uint32_t *vS = in_b ? valB : valA, *vT = in_b ? valA : valB;
+    const int e2 = tm.mark();
+
+    // A5: boundaries -> group starts -> ranks -> working set
+    hipLaunchKernelGGL(fwd::k_flag_boundaries, dim3(g256), dim3(256), 0, s, kS, n, v);
+    ARCHON_TRY(launch_scan<1>(s, v, v, n, scan_tmp, nullptr));
+    hipLaunchKernelGGL(fwd::k_scatter_rank, dim3(g256), dim3(256), 0, s, vS, v, n, sa, rank, keep);
+    ARCHON_TRY(launch_scan<0>(s, keep, dst, n, scan_tmp, d_total));
+    ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    c->launches += 8;
+    uint32_t m = c->h_mail[0];
+    st.unresolved_initial = m;
+    int cur = 0;
+    if (m) {
+        hipLaunchKernelGGL(fwd::k_compact_first, dim3(g256), dim3(256), 0, s, keep, dst, v, vS, n, upos[0], ug[0], uitem[0]);
+        ++c->launches;
+    }
+
+    // prefix doubling over the unresolved items
+    uint32_t h = fwd::kKeyBytes;
+    while (m) {
+        st.unresolved_total += m;
+        ++st.doubling_rounds;
+        const uint32_t gm = div_up(m, 256);
+        hipLaunchKernelGGL(fwd::k_gather_rank, dim3(gm), dim3(256), 0, s, ug[cur], uitem[cur], rank, h, m, kT, vT);
+        ARCHON_HIP_TRY(hipGetLastError());
+        bool b2 = false;
+        uint32_t passes = 0;
+        ARCHON_TRY(rs::sort_pairs(s, sc, kT, vT, kS, vS, m, 0xFFu, &b2, &passes, &c->launches));
+        uint64_t *kR = b2 ? kS : kT;
+        uint32_t *vR = b2 ? vS : vT;
+        hipLaunchKernelGGL(fwd::k_flag_round, dim3(gm), dim3(256), 0, s, kR, upos[cur], m, v);
+        ARCHON_TRY(launch_scan<1>(s, v, v, m, scan_tmp, nullptr));
+        hipLaunchKernelGGL(fwd::k_round_update, dim3(gm), dim3(256), 0, s, vR, upos[cur], v, m, sa, rank, keep);
+        ARCHON_TRY(launch_scan<0>(s, keep, dst, m, scan_tmp, d_total));
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        c->launches += 9;
+        const uint32_t m2 = c->h_mail[0];
+        if (m2) {
+            hipLaunchKernelGGL(fwd::k_compact_round, dim3(gm), dim3(256), 0, s, keep, dst, upos[cur], v, vR, m,
+                               upos[cur ^ 1], ug[cur ^ 1], uitem[cur ^ 1]);
+            ARCHON_HIP_TRY(hipGetLastError());
+            ++c->launches;
+        }
+        cur ^= 1;
+        m = m2;
+        if (h > n) {   // h >= n resolves everything; reaching here means an internal fault
+            if (m) { set_error("doubling did not converge (m=%u at h=%u)", m, h); return ARCHON_E_INTERNAL; }
+        }
+        h = h > 0x40000000u ? 0x80000000u : h * 2;
+    }
+    const int e3 = tm.mark();
+
+    // A7: SA -> BWT + primary index
+    hipLaunchKernelGGL(fwd::k_sa_to_bwt, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, sa, n, d_bwt, d_base);
+    ARCHON_HIP_TRY(hipGetLastError());
+    ++c->launches;
+    ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, d_base, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    const int e4 = tm.mark();
+    ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, sc.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    if (c->h_mail[0]) {
+        set_error("device consistency flag 0x%x (look-back spin bound)", c->h_mail[0]);
+        return ARCHON_E_INTERNAL;
+    }
+    st.ms_hist = tm.ms(e0, e1);
+    st.ms_sort = tm.ms(e1, e2);
+    st.ms_doubling = tm.ms(e2, e3);
+    st.ms_bwt = tm.ms(e3, e4);
+    st.ms_total = tm.ms(e0, e4);
+    st.kernel_launches = c->launches;
+    return ARCHON_OK;
+}
+
+}  // namespace archon
+
+// =====================================================================
+// C ABI
+// =====================================================================
+using namespace archon;
+
+extern "C" {
+
+int archon_hip_device_count(void) { return device_count(); }
+
+const char *archon_hip_last_error(void) { return t_err; }
+
+static int check_n(uint32_t n)
+{
+    if (n < 1 || n > ARCHON_HIP_MAX_N) {
+        set_error("block size %u out of range [1, %u]", n, ARCHON_HIP_MAX_N);
+        return ARCHON_E_ARG;
+    }
+    return ARCHON_OK;
+}
+
+int archon_hip_forward_dev(const uint8_t *d_x, uint32_t n, uint32_t *d_sa_or_null, uint8_t *d_bwt,
+                           uint32_t *d_base_id, int dev, void *stream)
+{
+    if (!d_x || !d_bwt || !d_base_id) { set_error("null pointer"); return ARCHON_E_ARG; }
+    ARCHON_TRY(check_n(n));
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+    return forward_run(c, s, d_x, n, d_sa_or_null, d_bwt, d_base_id);
+}
+
+int archon_hip_forward(const uint8_t *x, uint32_t n, uint32_t *sa_or_null, uint8_t *bwt, uint32_t *base_id, int dev)
+{
+    if (!x || !bwt || !base_id) { set_error("null pointer"); return ARCHON_E_ARG; }
+    ARCHON_TRY(check_n(n));
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = c->own_stream;
+    uint8_t *d_x = nullptr, *d_bwt = nullptr;
+    uint32_t *d_sa = nullptr, *d_base = nullptr;
+    int rc = ARCHON_OK;
+    auto cleanup = [&]() {
+        if (d_x) (void)hipFree(d_x);
+        if (d_bwt) (void)hipFree(d_bwt);
+        if (d_sa) (void)hipFree(d_sa);
+        if (d_base) (void)hipFree(d_base);
+    };
+    if (hipMalloc((void **)&d_x, (size_t)n + 64) != hipSuccess || hipMalloc((void **)&d_bwt, (size_t)n + 64) != hipSuccess ||
+        hipMalloc((void **)&d_base, 256) != hipSuccess ||
+        (sa_or_null && hipMalloc((void **)&d_sa, (size_t)n * 4) != hipSuccess)) {
+        (void)hipGetLastError();
+        cleanup();
+        set_error("device allocation failed for block of %u bytes", n);
+        return ARCHON_E_NOMEM;
+    }
+    hipError_t e = hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) rc = forward_run(c, s, d_x, n, d_sa, d_bwt, d_base);
+    if (e == hipSuccess && rc == ARCHON_OK) {
+        e = hipMemcpyAsync(bwt, d_bwt, n, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(base_id, d_base, 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && sa_or_null) e = hipMemcpyAsync(sa_or_null, d_sa, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    cleanup();
+    if (e != hipSuccess) { set_error("HIP copy failed: %s", hipGetErrorString(e)); return ARCHON_E_HIP; }
+    return rc;
+}
+
+int archon_hip_forward_keep(const uint8_t *x, uint32_t n, uint32_t *sa_or_null, uint32_t *base_id, int dev)
+{
+    if (!x || !base_id) { set_error("null pointer"); return ARCHON_E_ARG; }
+    ARCHON_TRY(check_n(n));
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = c->own_stream;
+    if (c->keep_bwt) { (void)hipFree(c->keep_bwt); c->keep_bwt = nullptr; c->keep_n = 0; }
+    uint8_t *d_x = nullptr;
+    uint32_t *d_sa = nullptr, *d_base = nullptr;
+    auto cleanup = [&]() {
+        if (d_x) (void)hipFree(d_x);
+        if (d_sa) (void)hipFree(d_sa);
+        if (d_base) (void)hipFree(d_base);
+    };
+    if (hipMalloc((void **)&d_x, (size_t)n + 64) != hipSuccess || hipMalloc((void **)&c->keep_bwt, (size_t)n + 64) != hipSuccess ||
+        hipMalloc((void **)&d_base, 256) != hipSuccess ||
+        (sa_or_null && hipMalloc((void **)&d_sa, (size_t)n * 4) != hipSuccess)) {
+        (void)hipGetLastError();
+        cleanup();
+        set_error("device allocation failed for block of %u bytes", n);
+        return ARCHON_E_NOMEM;
+    }
+    int rc = ARCHON_OK;
+    hipError_t e = hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) rc = forward_run(c, s, d_x, n, d_sa, c->keep_bwt, d_base);
+    if (e == hipSuccess && rc == ARCHON_OK) {
+        e = hipMemcpyAsync(base_id, d_base, 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && sa_or_null) e = hipMemcpyAsync(sa_or_null, d_sa, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    cleanup();
+    if (e != hipSuccess) { set_error("HIP copy failed: %s", hipGetErrorString(e)); return ARCHON_E_HIP; }
+    if (rc == ARCHON_OK) c->keep_n = n;
+    return rc;
+}
+
+int archon_hip_read_bwt(int dev, uint32_t offset, uint32_t len, uint8_t *dst)
+{
+    if (!dst) { set_error("null pointer"); return ARCHON_E_ARG; }
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    if (!c->keep_bwt || (uint64_t)offset + len > c->keep_n) { set_error("no resident BWT for that range"); return ARCHON_E_ARG; }
+    ARCHON_HIP_TRY(hipMemcpy(dst, c->keep_bwt + offset, len, hipMemcpyDeviceToHost));
+    return ARCHON_OK;
+}
+
+void *archon_hip_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (device_count() > 0 && hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess) return p;
+    (void)hipGetLastError();
+    return nullptr;
+}
+
+void archon_hip_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+int archon_hip_inverse_dev(const uint8_t *d_bwt, uint32_t n, uint32_t base_id, uint8_t *d_x_out, int dev, void *stream)
+{
+    if (!d_bwt || !d_x_out) { set_error("null pointer"); return ARCHON_E_ARG; }
+    ARCHON_TRY(check_n(n));
+    if (base_id >= n) { set_error("base_id %u >= n %u", base_id, n); return ARCHON_E_ARG; }
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+    return inverse_run(c, s, d_bwt, n, base_id, d_x_out);
+}
+
+int archon_hip_inverse(const uint8_t *bwt, uint32_t n, uint32_t base_id, uint8_t *x_out, int dev)
+{
+    if (!bwt || !x_out) { set_error("null pointer"); return ARCHON_E_ARG; }
+    ARCHON_TRY(check_n(n));
+    if (base_id >= n) { set_error("base_id %u >= n %u", base_id, n); return ARCHON_E_ARG; }
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = c->own_stream;
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    if (hipMalloc((void **)&d_in, (size_t)n + 64) != hipSuccess || hipMalloc((void **)&d_out, (size_t)n + 64) != hipSuccess) {
+        (void)hipGetLastError();
+        if (d_in) (void)hipFree(d_in);
+        set_error("device allocation failed for block of %u bytes", n);
+        return ARCHON_E_NOMEM;
+    }
+    int rc = ARCHON_OK;
+    hipError_t e = hipMemcpyAsync(d_in, bwt, n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) rc = inverse_run(c, s, d_in, n, base_id, d_out);
+    if (e == hipSuccess && rc == ARCHON_OK) {
+        e = hipMemcpyAsync(x_out, d_out, n, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) { set_error("HIP copy failed: %s", hipGetErrorString(e)); return ARCHON_E_HIP; }
+    return rc;
+}
+
+int archon_hip_hist256_dev(const uint8_t *d_x, size_t n, uint32_t *d_out256, int dev, void *stream)
+{
+    if (!d_x || !d_out256) { set_error("null pointer"); return ARCHON_E_ARG; }
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+    ARCHON_TRY(launch_hist256(s, d_x, n, d_out256, n));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    return ARCHON_OK;
+}
+
+int archon_hip_hist256(const uint8_t *x, size_t n, uint32_t out[256], int dev)
+{
+    if (!x || !out) { set_error("null pointer"); return ARCHON_E_ARG; }
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = c->own_stream;
+    uint8_t *d_x = nullptr;
+    ARCHON_HIP_TRY(hipMalloc((void **)&d_x, n + 64));
+    hipError_t e = hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s);
+    int rc = ARCHON_OK;
+    if (e == hipSuccess) rc = launch_hist256(s, d_x, n, c->d_mail, n);
+    if (e == hipSuccess && rc == ARCHON_OK) e = hipMemcpyAsync(out, c->d_mail, 256 * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_x);
+    if (e != hipSuccess) { set_error("HIP call failed: %s", hipGetErrorString(e)); return ARCHON_E_HIP; }
+    return rc;
+}
+
+int archon_hip_validate_dev(const uint8_t *d_x, uint32_t n, const uint32_t *d_sa, int dev, void *stream)
+{
+    if (!d_x || !d_sa) { set_error("null pointer"); return ARCHON_E_ARG; }
+    ARCHON_TRY(check_n(n));
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+    return validate_run(c, s, d_x, n, d_sa);
+}
+
+int archon_hip_validate(const uint8_t *x, uint32_t n, const uint32_t *sa, int dev)
+{
+    if (!x || !sa) { set_error("null pointer"); return ARCHON_E_ARG; }
+    ARCHON_TRY(check_n(n));
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = c->own_stream;
+    uint8_t *d_x = nullptr;
+    uint32_t *d_sa = nullptr;
+    if (hipMalloc((void **)&d_x, (size_t)n + 64) != hipSuccess || hipMalloc((void **)&d_sa, (size_t)n * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        if (d_x) (void)hipFree(d_x);
+        set_error("device allocation failed");
+        return ARCHON_E_NOMEM;
+    }
+    int rc = ARCHON_E_HIP;
+    if (hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s) == hipSuccess &&
+        hipMemcpyAsync(d_sa, sa, (size_t)n * 4, hipMemcpyHostToDevice, s) == hipSuccess)
+        rc = validate_run(c, s, d_x, n, d_sa);
+    else
+        set_error("HIP copy failed");
+    (void)hipFree(d_x);
+    (void)hipFree(d_sa);
+    return rc;
+}
+
+int archon_hip_radix_scatter_dev(const uint8_t *d_src, size_t n, uint8_t *d_dst, int dev, void *stream)
+{
+    if (!d_src || !d_dst) { set_error("null pointer"); return ARCHON_E_ARG; }
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+    uint32_t *d_counts = c->d_mail, *d_starts = c->d_mail + 256;
+    ARCHON_TRY(launch_hist256(s, d_src, n, d_counts, n));
+    hipLaunchKernelGGL(k_scan257, dim3(1), dim3(64), 0, s, d_counts, d_starts);
+    uint32_t grid = div_up(n, 256 * 16);
+    if (grid < 1) grid = 1;
+    if (grid > (uint32_t)kNumCU * 8) grid = kNumCU * 8;
+    hipLaunchKernelGGL(k_fill_runs, dim3(grid), dim3(256), 0, s, d_starts, d_dst, n);
+    ARCHON_HIP_TRY(hipGetLastError());
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    return ARCHON_OK;
+}
+
+int archon_hip_radix_scatter(const uint8_t *src, size_t n, uint8_t *dst, int dev)
+{
+    if (!src || !dst) { set_error("null pointer"); return ARCHON_E_ARG; }
+    if (n >= 0xFFFFFFFFull) { set_error("n too large"); return ARCHON_E_ARG; }
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    uint8_t *d_a = nullptr, *d_b = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        ARCHON_HIP_TRY(hipSetDevice(dev));
+        ARCHON_HIP_TRY(hipMalloc((void **)&d_a, n + 64));
+        if (hipMalloc((void **)&d_b, n + 64) != hipSuccess) { (void)hipFree(d_a); set_error("alloc"); return ARCHON_E_NOMEM; }
+        if (hipMemcpy(d_a, src, n, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d_a); (void)hipFree(d_b); set_error("copy"); return ARCHON_E_HIP; }
+    }
+    int rc = archon_hip_radix_scatter_dev(d_a, n, d_b, dev, nullptr);
+    if (rc == ARCHON_OK && hipMemcpy(dst, d_b, n, hipMemcpyDeviceToHost) != hipSuccess) { set_error("copy"); rc = ARCHON_E_HIP; }
+    (void)hipFree(d_a);
+    (void)hipFree(d_b);
+    return rc;
+}
+
+int archon_hip_reserve(uint32_t n, int dev, size_t *bytes_or_null)
+{
+    ARCHON_TRY(check_n(n));
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    size_t need = forward_arena_bytes(n);
+    const size_t inv = inverse_arena_bytes(n);
+    if (inv > need) need = inv;
+    ARCHON_TRY(ctx_ensure_arena(c, need));
+    if (bytes_or_null) *bytes_or_null = c->arena_bytes;
+    return ARCHON_OK;
+}
+
+int archon_hip_release(int dev)
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (dev < 0 || dev >= kMaxDev || !g_ctx[dev]) return ARCHON_OK;
+    Ctx *c = g_ctx[dev];
+    {
+        std::lock_guard<std::mutex> lk2(c->mu);
+        (void)hipSetDevice(dev);
+        (void)hipDeviceSynchronize();
+        if (c->arena) (void)hipFree(c->arena);
+        if (c->keep_bwt) (void)hipFree(c->keep_bwt);
+        if (c->d_mail) (void)hipFree(c->d_mail);
+        if (c->h_mail) (void)hipHostFree(c->h_mail);
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    }
+    delete c;
+    g_ctx[dev] = nullptr;
+    return ARCHON_OK;
+}
+
+int archon_hip_get_stats(int dev, archon_hip_stats *out)
+{
+    if (!out) { set_error("null pointer"); return ARCHON_E_ARG; }
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (dev < 0 || dev >= kMaxDev || !g_ctx[dev]) { set_error("no context on device %d", dev); return ARCHON_E_ARG; }
+    *out = g_ctx[dev]->stats;
+    return ARCHON_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+"""ctypes binding of libarchon_hip.so (include/archon_hip.h).
+
+Host-side plumbing for tests and bench.py only: numpy arrays for the host-buffer
+entry points, torch CUDA tensors (raw device pointers + the current HIP stream)
+for the device-resident ones.  There is no CPU fallback here or in the library:
+if the shared object is missing, importing raises; without a GPU every compute
+call returns ARCHON_E_NODEVICE and this module raises ArchonError.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libarchon_hip.so")
+
+OK, E_ARG, E_NODEVICE, E_NOMEM, E_HIP, E_INTERNAL, E_CORRUPT = 0, -1, -2, -3, -4, -5, -6
+MAX_N = 0x3FFFFF00
+
+SYMBOLS = [
+    "archon_hip_device_count", "archon_hip_last_error",
+    "archon_hip_forward", "archon_hip_inverse", "archon_hip_hist256",
+    "archon_hip_validate", "archon_hip_radix_scatter",
+    "archon_hip_forward_keep", "archon_hip_read_bwt", "archon_hip_host_alloc", "archon_hip_host_free",
+    "archon_hip_forward_dev", "archon_hip_inverse_dev", "archon_hip_hist256_dev",
+    "archon_hip_validate_dev", "archon_hip_radix_scatter_dev",
+    "archon_hip_reserve", "archon_hip_release", "archon_hip_get_stats",
+]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_uint32), ("radix_passes", ctypes.c_uint32), ("doubling_rounds", ctypes.c_uint32),
+        ("_pad0", ctypes.c_uint32),
+        ("unresolved_initial", ctypes.c_uint64), ("unresolved_total", ctypes.c_uint64),
+        ("ms_total", ctypes.c_float), ("ms_hist", ctypes.c_float), ("ms_sort", ctypes.c_float),
+        ("ms_doubling", ctypes.c_float), ("ms_bwt", ctypes.c_float), ("ms_lf_build", ctypes.c_float),
+        ("ms_lf_walk", ctypes.c_float), ("_pad1", ctypes.c_uint32),
+        ("walk_chains", ctypes.c_uint64), ("kernel_launches", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+    ]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("_")}
+
+
+class ArchonError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("archon_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libarchon_hip.so not built: run `make lib` (hipcc, gfx950); there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, u32, i32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_size_t
+    lib.archon_hip_device_count.restype = i32
+    lib.archon_hip_last_error.restype = ctypes.c_char_p
+    for name, args in {
+        "archon_hip_forward": [vp, u32, vp, vp, vp, i32],
+        "archon_hip_inverse": [vp, u32, u32, vp, i32],
+        "archon_hip_hist256": [vp, sz, vp, i32],
+        "archon_hip_validate": [vp, u32, vp, i32],
+        "archon_hip_radix_scatter": [vp, sz, vp, i32],
+        "archon_hip_forward_dev": [vp, u32, vp, vp, vp, i32, vp],
+        "archon_hip_inverse_dev": [vp, u32, u32, vp, i32, vp],
+        "archon_hip_hist256_dev": [vp, sz, vp, i32, vp],
+        "archon_hip_validate_dev": [vp, u32, vp, i32, vp],
+        "archon_hip_radix_scatter_dev": [vp, sz, vp, i32, vp],
+        "archon_hip_reserve": [u32, i32, vp],
+        "archon_hip_release": [i32],
+        "archon_hip_get_stats": [i32, ctypes.POINTER(Stats)],
+    }.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = i32
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise ArchonError(rc, lib().archon_hip_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def device_count():
+    return lib().archon_hip_device_count()
+
+
+# ---------------------------------------------------------------- host buffers (numpy)
+def forward(x, want_sa=True, dev=0):
+    """x: uint8 array -> (sa or None, bwt, base_id).  Archon::enCompute + enWrite semantics."""
+    x = np.ascontiguousarray(x, dtype=np.uint8)
+    n = x.size
+    sa = np.empty(n, dtype=np.uint32) if want_sa else None
+    bwt = np.empty(n, dtype=np.uint8)
+    base = ctypes.c_uint32(0)
+    _check(lib().archon_hip_forward(_p(x), n, _p(sa) if want_sa else None, _p(bwt),
+                                    ctypes.cast(ctypes.byref(base), ctypes.c_void_p), dev))
+    return sa, bwt, base.value
+
+
+def inverse(bwt, base_id, dev=0):
+    """bwt + base_id -> x.  Archon::deCompute + deWrite semantics."""
+    bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
+    out = np.empty(bwt.size, dtype=np.uint8)
+    _check(lib().archon_hip_inverse(_p(bwt), bwt.size, int(base_id), _p(out), dev))
+    return out
+
+
+def hist256(x, dev=0):
+    x = np.ascontiguousarray(x, dtype=np.uint8)
+    out = np.zeros(256, dtype=np.uint32)
+    _check(lib().archon_hip_hist256(_p(x), x.size, _p(out), dev))
+    return out
+
+
+def validate(x, sa, dev=0):
+    x = np.ascontiguousarray(x, dtype=np.uint8)
+    sa = np.ascontiguousarray(sa, dtype=np.uint32)
+    return bool(_check(lib().archon_hip_validate(_p(x), x.size, _p(sa), dev)))
+
+
+def radix_scatter(src, dev=0):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.empty_like(src)
+    _check(lib().archon_hip_radix_scatter(_p(src), src.size, _p(dst), dev))
+    return dst
+
+
+def stats(dev=0):
+    s = Stats()
+    _check(lib().archon_hip_get_stats(dev, ctypes.byref(s)))
+    return s.asdict()
+
+
+def reserve(n, dev=0):
+    b = ctypes.c_size_t(0)
+    _check(lib().archon_hip_reserve(n, dev, ctypes.cast(ctypes.byref(b), ctypes.c_void_p)))
+    return b.value
+
+
+# ---------------------------------------------------------------- device resident (torch)
+def _stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def forward_dev(x_t, sa_t, bwt_t, base_t):
+    """torch CUDA tensors: x uint8[n], sa int32[n] or None, bwt uint8[n], base int32[1]."""
+    dev = x_t.device.index or 0
+    _check(lib().archon_hip_forward_dev(ctypes.c_void_p(x_t.data_ptr()), x_t.numel(),
+                                        ctypes.c_void_p(sa_t.data_ptr()) if sa_t is not None else None,
+                                        ctypes.c_void_p(bwt_t.data_ptr()), ctypes.c_void_p(base_t.data_ptr()),
+                                        dev, _stream_ptr()))
+
+
+def inverse_dev(bwt_t, base_id, out_t):
+    dev = bwt_t.device.index or 0
+    _check(lib().archon_hip_inverse_dev(ctypes.c_void_p(bwt_t.data_ptr()), bwt_t.numel(), int(base_id),
+                                        ctypes.c_void_p(out_t.data_ptr()), dev, _stream_ptr()))
+
+
+def hist256_dev(x_t, out_t):
+    dev = x_t.device.index or 0
+    _check(lib().archon_hip_hist256_dev(ctypes.c_void_p(x_t.data_ptr()), x_t.numel(),
+                                        ctypes.c_void_p(out_t.data_ptr()), dev, _stream_ptr()))
+
+
+def validate_dev(x_t, sa_t):
+    dev = x_t.device.index or 0
+    return bool(_check(lib().archon_hip_validate_dev(ctypes.c_void_p(x_t.data_ptr()), x_t.numel(),
+                                                     ctypes.c_void_p(sa_t.data_ptr()), dev, _stream_ptr())))

@@ -1,0 +1,137 @@
+/*
+ * archon_hip.h -- C ABI of libarchon_hip.so: the MI355X (gfx950) kernels behind
+ * the Archon a7 BWT hot path.  Plain pointers and sizes, no exceptions, no
+ * torch/HIP types in any signature (a HIP stream crosses as void*).
+ *
+ * What each entry point replaces in kvark/dark-archon (paths under bwt/a7/src):
+ *
+ *   archon_hip_forward      Archon::enCompute (archon.cpp:882-885 -> Constructor<byte>
+ *                           784-819) + the gather loop of Archon::enWrite (887-900)
+ *   archon_hip_inverse      Archon::deCompute (917-935) + the LF walk of Archon::deWrite (937-943)
+ *   archon_hip_hist256      Constructor::makeBuckets (118-126); tool/radix_dir/radix.c:31-36
+ *   archon_hip_validate     Archon::validate (862-874)
+ *   archon_hip_radix_scatter  the counting-sort scatter of tool/radix_dir/radix.c:40-44
+ *
+ * Ordering convention ("a7 order"): item s in 1..N names the
+ * reversed prefix x[s-1],x[s-2],...,x[0],INF with INF > 255; sa[0..N) lists the
+ * items in ascending key order; bwt[i] = x[sa[i]] (x[0] where sa[i]==N);
+ * *base_id = the i with sa[i]==N.
+ *
+ * Error model: 0 = ok, negative = ARCHON_E_* below (the reference returns int
+ * from every Archon method, archon.h:16-28).  The library owns device memory and
+ * streams (one context per device, created lazily, serialised by a per-device
+ * mutex so separate host threads may drive separate devices concurrently);
+ * callers own every buffer they pass.  There is NO CPU fallback: without a HIP
+ * device every compute entry point returns ARCHON_E_NODEVICE.
+ *
+ * Limits: 1 <= n <= ARCHON_HIP_MAX_N (the reference needs n < 2^30 for its
+ * default tracking path, archon.cpp:802).
+ */
+#ifndef ARCHON_HIP_H
+#define ARCHON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARCHON_HIP_MAX_N      0x3FFFFF00u
+
+#define ARCHON_OK             0
+#define ARCHON_E_ARG        (-1)   /* null pointer / n out of range / bad base_id */
+#define ARCHON_E_NODEVICE   (-2)   /* no HIP device, or dev out of range */
+#define ARCHON_E_NOMEM      (-3)   /* device or host allocation failed */
+#define ARCHON_E_HIP        (-4)   /* a HIP runtime call failed (see archon_hip_last_error) */
+#define ARCHON_E_INTERNAL   (-5)   /* device-side consistency flag raised (e.g. look-back spin bound) */
+#define ARCHON_E_CORRUPT    (-6)   /* inverse: LF walk does not close (not a BWT of this format) */
+
+/* number of HIP devices visible (0 when none); never fails */
+int archon_hip_device_count(void);
+
+/* human-readable text for the last error raised on the calling thread */
+const char *archon_hip_last_error(void);
+
+/* ---- host-buffer entry points (what the C host / cgo-style bindings call) ---- */
+
+/* x[n] -> sa (optional, may be NULL), bwt[n], *base_id.  All host pointers. */
+int archon_hip_forward(const uint8_t *x, uint32_t n, uint32_t *sa_or_null,
+                       uint8_t *bwt, uint32_t *base_id, int dev);
+
+/* Block-coder form used by the host object (include/archon.h), which must stay
+ * within the reference's 5N + O(1) host bytes: the suffix array goes to sa[n], the
+ * BWT stays resident in HBM and is read back in pieces through any O(1) bounce
+ * buffer with archon_hip_read_bwt (valid until the next call on `dev`). */
+int archon_hip_forward_keep(const uint8_t *x, uint32_t n, uint32_t *sa_or_null,
+                            uint32_t *base_id, int dev);
+int archon_hip_read_bwt(int dev, uint32_t offset, uint32_t len, uint8_t *dst);
+
+/* pinned host memory for block buffers (faster PCIe copies); plain malloc works too */
+void *archon_hip_host_alloc(size_t bytes);
+void archon_hip_host_free(void *p);
+
+/* bwt[n] + base_id -> x_out[n].  All host pointers. */
+int archon_hip_inverse(const uint8_t *bwt, uint32_t n, uint32_t base_id,
+                       uint8_t *x_out, int dev);
+
+/* 256-bin histogram of x[n] (host pointers). */
+int archon_hip_hist256(const uint8_t *x, size_t n, uint32_t out[256], int dev);
+
+/* LF-consistency of sa against x; returns 1 = consistent, 0 = not, <0 = error. */
+int archon_hip_validate(const uint8_t *x, uint32_t n, const uint32_t *sa, int dev);
+
+/* dst = src stably sorted by byte value (tool/radix_dir scatter), host pointers. */
+int archon_hip_radix_scatter(const uint8_t *src, size_t n, uint8_t *dst, int dev);
+
+/* ---- device-resident entry points (inputs already in HBM) ---------------------
+ * Every pointer is a device pointer on device `dev`; `stream` is a hipStream_t
+ * passed as void* (NULL = the context's own stream).  Work is enqueued on that
+ * stream; the forward/inverse pipelines contain host-side decision points
+ * (number of unresolved suffix groups), so these calls synchronise the stream
+ * internally and the outputs are complete when they return. */
+int archon_hip_forward_dev(const uint8_t *d_x, uint32_t n, uint32_t *d_sa_or_null,
+                           uint8_t *d_bwt, uint32_t *d_base_id, int dev, void *stream);
+int archon_hip_inverse_dev(const uint8_t *d_bwt, uint32_t n, uint32_t base_id,
+                           uint8_t *d_x_out, int dev, void *stream);
+int archon_hip_hist256_dev(const uint8_t *d_x, size_t n, uint32_t *d_out256, int dev, void *stream);
+int archon_hip_validate_dev(const uint8_t *d_x, uint32_t n, const uint32_t *d_sa, int dev, void *stream);
+int archon_hip_radix_scatter_dev(const uint8_t *d_src, size_t n, uint8_t *d_dst, int dev, void *stream);
+
+/* ---- workspace / lifetime ---------------------------------------------------- */
+
+/* Pre-size the per-device arena for blocks up to n bytes (optional; the arena
+ * grows on demand).  Returns bytes reserved via *bytes_or_null. */
+int archon_hip_reserve(uint32_t n, int dev, size_t *bytes_or_null);
+
+/* Free the per-device context (arena, streams, events). */
+int archon_hip_release(int dev);
+
+/* ---- measurement ------------------------------------------------------------- */
+
+/* Per-stage device times (HIP events on the stream the kernels ran on) and
+ * work counters of the most recent forward/inverse call on `dev`. */
+typedef struct archon_hip_stats {
+    uint32_t n;                  /* block size of the call */
+    uint32_t radix_passes;       /* LSB radix passes executed by the first-stage sort */
+    uint32_t doubling_rounds;    /* prefix-doubling rounds executed */
+    uint64_t unresolved_initial; /* items left tied by the first stage */
+    uint64_t unresolved_total;   /* sum over rounds of items entering a round */
+    float ms_total;              /* whole device pipeline */
+    float ms_hist;               /* hist256 / bucket setup */
+    float ms_sort;               /* first-stage radix bucketing */
+    float ms_doubling;           /* prefix-doubling refinement */
+    float ms_bwt;                /* sa_to_bwt */
+    float ms_lf_build;           /* inverse: LF table */
+    float ms_lf_walk;            /* inverse: chain walk */
+    uint64_t walk_chains;        /* inverse: number of sub-chains walked in parallel */
+    uint32_t kernel_launches;    /* launches issued by the call */
+    uint32_t reserved;
+} archon_hip_stats;
+
+int archon_hip_get_stats(int dev, archon_hip_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,116 @@
+"""GPU parity: the HIP forward path through the C ABI vs the CPU oracle (bit-exact)."""
+import itertools
+
+import numpy as np
+import pytest
+
+import archon_synth as S
+
+pytestmark = pytest.mark.gpu
+
+KNOWN = {
+    b"abracadabra": ([6, 8, 11, 4, 1, 9, 2, 5, 7, 10, 3], b"dbacbrraaaa", 2),
+    b"mississippi": ([2, 11, 5, 8, 1, 9, 10, 3, 6, 4, 7], b"smspipissii", 1),
+    b"banana": ([2, 4, 6, 1, 3, 5], b"nnbaaa", 2),
+    b"aaaa": ([4, 3, 2, 1], b"aaaa", 0),
+    b"abab": ([3, 1, 4, 2], b"bbaa", 2),
+    b"baba": ([4, 2, 3, 1], b"bbaa", 0),
+    bytes([0, 255, 0, 255, 255]): ([3, 1, 4, 2, 5], bytes([255, 255, 255, 0, 0]), 4),
+    b"ab": ([1, 2], b"ba", 1),
+    b"ba": ([2, 1], b"ba", 0),
+    b"a": ([1], b"a", 0),
+}
+
+
+def test_known_answers(archon):
+    """SURVEY.md 8(a0) known answers (cross-checked against a7 / a6 there)."""
+    for s, (P, B, base) in KNOWN.items():
+        x = np.frombuffer(s, np.uint8)
+        sa, bwt, b = archon.forward(x)
+        assert list(sa) == P and bwt.tobytes() == B and b == base, s
+
+
+def test_exhaustive_small(archon, oracle):
+    """every string over {0,1}^<=8, {0,1,2}^<=5, {254,255}^<=8: SA equals the definition"""
+    for alpha, maxlen in (((0, 1), 8), ((0, 1, 2), 5), ((254, 255), 8)):
+        for n in range(1, maxlen + 1):
+            for t in itertools.product(alpha, repeat=n):
+                x = np.array(t, np.uint8)
+                sa, bwt, b = archon.forward(x)
+                assert (sa == oracle.sa(x, brute=True)).all(), t
+
+
+@pytest.mark.parametrize("shape", S.SHAPES)
+@pytest.mark.parametrize("n", [1000, 65536, 1 << 20])
+def test_shapes_vs_oracle(archon, oracle, shape, n):
+    x = S.gen_shape(shape, n)
+    sa, bwt, base = archon.forward(x)
+    P, B, b0 = oracle.forward(x)
+    assert (sa == P).all()
+    assert (bwt == B).all() and base == b0
+    assert archon.validate(x, sa)
+
+
+def test_ff_heavy(archon, oracle):
+    """0xFF runs exercise the end-of-string-above-255 rule (padding ties)."""
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 7, 8, 9, 15, 64, 1000, 5000):
+        x = np.full(n, 255, np.uint8)
+        sa, _, _ = archon.forward(x)
+        assert (sa == oracle.sa(x)).all(), n
+        y = rng.choice(np.array([254, 255], np.uint8), size=n, p=[0.1, 0.9])
+        sa, _, _ = archon.forward(y)
+        assert (sa == oracle.sa(y)).all(), n
+
+
+def test_ragged_sizes(archon, oracle):
+    rng = np.random.default_rng(7)
+    for n in (3, 5, 63, 64, 65, 255, 257, 4095, 4097, 8191, 8193, 16385, 100003):
+        x = rng.integers(0, 4, size=n, dtype=np.uint8)
+        sa, bwt, base = archon.forward(x)
+        P, B, b0 = oracle.forward(x)
+        assert (sa == P).all() and (bwt == B).all() and base == b0, n
+
+
+def test_bwt_without_sa(archon, oracle):
+    x = S.gen_text(50000)
+    sa, bwt, base = archon.forward(x, want_sa=False)
+    assert sa is None
+    P, B, b0 = oracle.forward(x)
+    assert (bwt == B).all() and base == b0
+
+
+def test_hist256(archon, oracle):
+    for shape in ("random", "a", "text"):
+        for n in (1, 15, 17, 4096, 1 << 20, (1 << 20) + 13):
+            x = S.gen_shape(shape, n)
+            assert (archon.hist256(x) == oracle.hist256(x)[0]).all()
+
+
+def test_radix_scatter(archon, oracle):
+    x = S.gen_random(1 << 15)
+    assert (archon.radix_scatter(x) == oracle.radix_scatter(x)).all()
+
+
+def test_validate_rejects(archon, oracle):
+    x = S.gen_text(10000)
+    P = oracle.sa(x)
+    assert archon.validate(x, P)
+    Q = P.copy()
+    Q[[10, 11]] = Q[[11, 10]]
+    assert not archon.validate(x, Q)
+    Q = P.copy()
+    Q[5] = 0
+    assert not archon.validate(x, Q)
+
+
+def test_errors(archon):
+    import ctypes
+    L = archon.lib()
+    assert L.archon_hip_forward(None, 10, None, None, None, 0) == archon.E_ARG
+    x = np.zeros(4, np.uint8)
+    b = np.zeros(4, np.uint8)
+    base = ctypes.c_uint32()
+    bp = ctypes.cast(ctypes.byref(base), ctypes.c_void_p)
+    assert L.archon_hip_forward(ctypes.c_void_p(x.ctypes.data), 0, None, ctypes.c_void_p(b.ctypes.data), bp, 0) == archon.E_ARG
+    assert L.archon_hip_forward(ctypes.c_void_p(x.ctypes.data), 4, None, ctypes.c_void_p(b.ctypes.data), bp, 99) == archon.E_NODEVICE
