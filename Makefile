@@ -10,12 +10,19 @@ CSRC       = $(PKG)/csrc
 HIPFLAGS   = -O3 --offload-arch=$(ARCH) -std=c++17 -fPIC -Wall -Wno-unused-function
 LIB        = $(PKG)/libarchon_hip.so
 
-all: lib cli oracle
+all: lib host cli oracle
 
 lib: $(LIB)
 
 $(LIB): $(CSRC)/archon_hip.hip $(wildcard $(CSRC)/*.hiph) include/archon_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/archon_hip.hip
+
+host: $(PKG)/libarchon.so
+
+# the block-coder object (include/archon.h) as a shared library for FFI callers
+$(PKG)/libarchon.so: $(PKG)/host/archon_host.cpp $(PKG)/host/archon_host.h include/archon.h $(LIB)
+	$(CXX) -O2 -std=c++17 -Wall -fPIC -shared -Iinclude -o $@ $(PKG)/host/archon_host.cpp \
+	    -L$(PKG) -larchon_hip -Wl,-rpath,'$$ORIGIN'
 
 cli: bin/archon
 
@@ -28,7 +35,7 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -rf bin $(LIB)
+	rm -rf bin $(LIB) $(PKG)/libarchon.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib cli oracle clean
+.PHONY: all lib host cli oracle clean

@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- forward-BWT throughput of the MI355X path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: every
+rank runs the whole forward pipeline (hist256 -> LSB radix bucketing -> prefix
+doubling -> sa_to_bwt, SA emitted) on its own 256 MiB block of uniform random
+bytes already resident in HBM (BASELINE.json configs[1], SURVEY.md 8(d) cfg 2;
+block b is seeded SEED_BASE+2+b), and for N>1 the per-block outputs BWT||baseId
+are gathered to rank 0 over RCCL (the path's one exchange step).
+Blocks are independent, per-GPU work is fixed: "scaling": "weak".
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline      the dominant kernel (one LSB radix pass, rs::k_scatter): algorithmic
+                bytes per launch (9 B x N) / its mean launch time, taken
+                live from HIP events recorded around each launch on the kernel's stream
+  cpu_baseline  the reference a7 (oracle/_ref/a7ref, built from /root/reference by
+                oracle/Makefile; kind "reference") or, when that binary is absent, the
+                repo's CPU oracle (kind "port"), single thread, on a bounded sample of
+                the same workload, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "dark-archon_amd"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+B_FWD_CFG2 = 57.0              # algorithmic bytes per input byte, config 2 (D = 6)
+B_RADIX_PASS = 9.0             # per item per LSB pass (read idx 4 + digit 1, write idx 4)
+
+
+def cpu_baseline(block_bytes):
+    """Single-thread CPU figure on a bounded sample (about 10-30 s of CPU work)."""
+    import archon_synth
+    ref = os.path.join(ROOT, "oracle", "_ref", "a7ref")
+    sample_n = min(block_bytes, 64 << 20)
+    x = archon_synth.gen_random(sample_n)
+    sample = "first %d MiB of the rank-0 block (uniform random bytes), SA+BWT, clock() around compute" % (sample_n >> 20)
+    if os.path.exists(ref):
+        tag = "/tmp/bench_a7ref_%d" % os.getpid()
+        x.tofile(tag + ".in")
+        try:
+            r = subprocess.run([ref, "e", tag + ".in", tag + ".bwt"], capture_output=True, text=True, timeout=600)
+            kv = dict(t.split("=") for t in r.stdout.split())
+            if r.returncode == 0 and int(kv.get("validate", "0")) == 1:
+                secs = float(kv["sa_time"])
+                return {"value": round(sample_n / 1e6 / secs, 3), "unit": "MB/s", "cores": 1, "kind": "reference",
+                        "sample": sample + "; reference a7 -O3 (oracle/_ref/a7ref)",
+                        "host_cores": os.cpu_count()}
+        except Exception:
+            pass
+        finally:
+            for ext in (".in", ".bwt"):
+                if os.path.exists(tag + ext):
+                    os.remove(tag + ext)
+    # port: the repo's own CPU restatement (oracle/), checker used as a timed baseline only
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding
+    orc = oracle_binding.Oracle()
+    sample_n = min(sample_n, 32 << 20)
+    x = x[:sample_n]
+    t0 = orc.L.oracle_clock_seconds()
+    orc.forward(x)
+    secs = orc.L.oracle_clock_seconds() - t0
+    return {"value": round(sample_n / 1e6 / secs, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+            "sample": "first %d MiB of the rank-0 block; oracle/archon_oracle.c" % (sample_n >> 20),
+            "host_cores": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--block-mib", type=int, default=256, help="block size per GPU (BASELINE config: 256)")
+    ap.add_argument("--shape", default="random", help="random|dna|text|a|ab|motif (graded config: random)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sa", action="store_true", help="emit BWT only (the metric is quoted WITH the SA)")
+    args = ap.parse_args()
+
+    import torch
+    import archon_synth
+    import pyarchon
+
+    pyarchon.lib()   # fail loudly if the HIP extension is missing
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+
+    n = args.block_mib << 20
+    x = archon_synth.gen_shape(args.shape, n, block=rank)
+    x_t = torch.from_numpy(x).to(dev)
+    sa_t = None if args.no_sa else torch.empty(n, dtype=torch.int32, device=dev)
+    out_t = torch.empty(n + 4, dtype=torch.uint8, device=dev)       # BWT || baseId (LE)
+    base_t = torch.zeros(1, dtype=torch.int32, device=dev)
+    gather_list = None
+    if dist is not None and rank == 0:
+        gather_list = [torch.empty(n + 4, dtype=torch.uint8, device=dev) for _ in range(world)]
+    pyarchon.reserve(n, local_rank)
+
+    pass_ms, pass_cnt, stage = [], [], []
+
+    def step():
+        pyarchon.forward_dev(x_t, sa_t, out_t[:n], base_t)
+        out_t[n:] = base_t.view(torch.uint8)
+        st = pyarchon.stats(local_rank)
+        pass_ms.append(st["ms_radix_pass_sum"])
+        pass_cnt.append(st["radix_pass_timed"])
+        stage.append(st)
+        if dist is not None:
+            dist.gather(out_t, gather_list, dst=0)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    del pass_ms[:], pass_cnt[:], stage[:]
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # correctness gate on the timed output: LF-consistency of the SA on the device
+    ok = True
+    if sa_t is not None:
+        ok = pyarchon.validate_dev(x_t, sa_t)
+    if dist is not None:
+        flag = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+
+    if rank == 0:
+        ms_per_step = dt * 1e3 / args.steps
+        total_bytes = float(n) * world * args.steps
+        value = total_bytes / 1e6 / dt
+        npass = max(1, sum(pass_cnt))
+        t_pass_ms = sum(pass_ms) / npass
+        achieved = B_RADIX_PASS * n / (t_pass_ms * 1e-3) / 1e9 if t_pass_ms > 0 else 0.0
+        last = stage[-1]
+        dev_ms = float(np.mean([s["ms_total"] for s in stage]))
+        line = {
+            "metric": "forward-BWT MB/s on 256 MB block (SA bit-exact vs a7 order)",
+            "value": round(value, 1),
+            "unit": "MB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: %d MiB uniform-random bytes (splitmix64, seed 0x20261003+2+rank), one BWT block per GPU, SA+BWT+baseId emitted"
+                            % args.block_mib if args.shape == "random" else "%d MiB '%s' block per GPU" % (args.block_mib, args.shape),
+                "block_bytes": n,
+                "blocks_per_step": world,
+                "parallelism": "block-sharded x%d, one RCCL gather of BWT||baseId per step" % world if world > 1 else "single GPU",
+                "sa_emitted": sa_t is not None,
+                "sa_lf_consistent": ok,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "rs::k_scatter (one LSB radix pass over %d items)" % n,
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "launch_ms": round(t_pass_ms, 4),
+                "launches_per_step": last["radix_pass_timed"],
+                "algorithmic_bytes_per_launch": B_RADIX_PASS * n,
+            },
+            "pipeline": {
+                "device_ms_per_block": round(dev_ms, 3),
+                "algorithmic_bytes_per_input_byte": B_FWD_CFG2,
+                "frac_of_hbm_roofline": round(B_FWD_CFG2 * n / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dev_ms > 0 else None,
+                "ms_hist": round(last["ms_hist"], 3), "ms_sort": round(last["ms_sort"], 3),
+                "ms_doubling": round(last["ms_doubling"], 3), "ms_bwt": round(last["ms_bwt"], 3),
+                "radix_passes": last["radix_passes"], "doubling_rounds": last["doubling_rounds"],
+                "unresolved_initial": last["unresolved_initial"], "kernel_launches": last["kernel_launches"],
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(n)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

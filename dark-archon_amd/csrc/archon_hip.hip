@@ -164,7 +164,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     ARCHON_HIP_TRY(hipGetLastError());
     ++c->launches;
     bool in_b = false;
-    ARCHON_TRY(rs::sort_pairs(s, sc, keyA, valA, keyB, valB, n, 0xFEu, &in_b, &st.radix_passes, &c->launches));
+    StageTimer pt(s);
+    ARCHON_TRY(rs::sort_pairs(s, sc, keyA, valA, keyB, valB, n, 0xFEu, &in_b, &st.radix_passes, &c->launches, &pt));
     uint64_t *kS = in_b ? keyB : keyA, *kT = in_b ? keyA : keyB;
     uint32_t *vS = in_b ? valB : valA, *vT = in_b ? valA : valB;
     const int e2 = tm.mark();
@@ -239,6 +240,10 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     st.ms_bwt = tm.ms(e3, e4);
     st.ms_total = tm.ms(e0, e4);
     st.kernel_launches = c->launches;
+    for (int i = 0; i + 1 < pt.n; i += 2) {
+        st.ms_radix_pass_sum += pt.ms(i, i + 1);
+        ++st.radix_pass_timed;
+    }
     return ARCHON_OK;
 }
 

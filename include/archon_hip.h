@@ -126,7 +126,9 @@ typedef struct archon_hip_stats {
     float ms_lf_walk;            /* inverse: chain walk */
     uint64_t walk_chains;        /* inverse: number of sub-chains walked in parallel */
     uint32_t kernel_launches;    /* launches issued by the call */
-    uint32_t reserved;
+    uint32_t radix_pass_timed;   /* first-stage radix passes bracketed by their own HIP events */
+    float ms_radix_pass_sum;     /* device time inside those passes (k_scatter only) */
+    float ms_reserved;
 } archon_hip_stats;
 
 int archon_hip_get_stats(int dev, archon_hip_stats *out);

@@ -1,0 +1,100 @@
+"""CPU: the C-ABI shared libraries load and export every symbol their headers declare;
+without a GPU the compute entry points fail loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(archon_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_hip_library_exports_header():
+    import pyarchon
+    lib = pyarchon.lib()
+    names = declared_functions("archon_hip.h")
+    assert len(names) >= 18
+    for name in names:
+        assert hasattr(lib, name), name
+    assert set(pyarchon.SYMBOLS) <= set(names)
+
+
+def test_host_library_exports_header():
+    path = os.path.join(ROOT, "dark-archon_amd", "libarchon.so")
+    if not os.path.exists(path):
+        subprocess.run(["make", "-C", ROOT, "host"], check=True, capture_output=True)
+    lib = ctypes.CDLL(path)
+    for name in declared_functions("archon.h"):
+        assert hasattr(lib, name), name
+
+
+def test_stats_struct_size():
+    import pyarchon
+    assert ctypes.sizeof(pyarchon.Stats) == 88   # sizeof(archon_hip_stats)
+
+
+def test_no_cpu_fallback():
+    """On a box without a GPU every compute call returns ARCHON_E_NODEVICE; on a GPU box
+    this test checks argument validation instead."""
+    import pyarchon
+    L = pyarchon.lib()
+    x = np.frombuffer(b"banana", np.uint8).copy()
+    bwt = np.zeros(6, np.uint8)
+    base = ctypes.c_uint32()
+    rc = L.archon_hip_forward(ctypes.c_void_p(x.ctypes.data), 6, None, ctypes.c_void_p(bwt.ctypes.data),
+                              ctypes.cast(ctypes.byref(base), ctypes.c_void_p), 0)
+    if pyarchon.device_count() == 0:
+        assert rc == pyarchon.E_NODEVICE
+        assert b"no CPU fallback" in L.archon_hip_last_error()
+        with pytest.raises(pyarchon.ArchonError):
+            pyarchon.forward(x)
+        with pytest.raises(pyarchon.ArchonError):
+            pyarchon.inverse(x, 0)
+        with pytest.raises(pyarchon.ArchonError):
+            pyarchon.hist256(x)
+    else:
+        assert rc == 0 and bwt.tobytes() == b"nnbaaa" and base.value == 2
+    assert L.archon_hip_forward(None, 6, None, None, None, 0) == pyarchon.E_ARG
+
+
+def test_cli_usage_codes(tmp_path):
+    """a7 main.cpp return codes: -1 usage, -2 cannot open input, -3 empty input"""
+    exe = os.path.join(ROOT, "bin", "archon")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", ROOT, "cli"], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 255 and "Usage: archon [e|d] <in> <out>" in r.stdout
+    r = subprocess.run([exe, "x", "a", "b"], capture_output=True, text=True)
+    assert r.returncode == 255
+    r = subprocess.run([exe, "e", str(tmp_path / "missing"), str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 254
+    (tmp_path / "empty").write_bytes(b"")
+    r = subprocess.run([exe, "e", str(tmp_path / "empty"), str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 253
+    (tmp_path / "short").write_bytes(b"abc")
+    r = subprocess.run([exe, "d", str(tmp_path / "short"), str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 254
+
+
+def test_synth_generators_are_deterministic():
+    import archon_synth as S
+    import hashlib
+    a = S.gen_random(1000)
+    assert (a == S.gen_random(2000)[:1000]).all()
+    assert hashlib.sha256(S.gen_random(4096).tobytes()).hexdigest() == hashlib.sha256(S.gen_random(4096).tobytes()).hexdigest()
+    d = S.gen_dna(5000)
+    assert set(np.unique(d)) <= set(b"ACGT")
+    t = S.gen_text(20000)
+    assert t.min() >= 10 and t.max() < 127 and (t == 32).mean() > 0.1
+    assert S.gen_repeat(5, b"ab").tobytes() == b"ababa"
+    assert (S.gen_motif(3000)[:1000] == S.gen_motif(3000)[1000:2000]).all()
+    # splitmix64 known value: first output for seed 0 is 0xE220A8397B1DCDAF
+    assert int(S.splitmix64_words(0, 0, 1)[0]) == 0xE220A8397B1DCDAF
