@@ -1,0 +1,70 @@
+"""Block sharding over the GPUs of one node.
+
+A block is a self-contained BWT (one block per file in a7/a4/a6; a sequence of
+independent blocks each with its own index in x1-x3, bwt/final/x3/archon.c:122-125),
+so the path shards with no cross-block merge: block b -> rank b mod G, every rank
+runs the whole single-GPU pipeline on its blocks, and ONE collective gathers the
+per-block payloads BWT||baseId (N+4 bytes) on rank 0.  The collective is issued
+through torch.distributed: backend "nccl" is RCCL over xGMI on the GPU node, "gloo"
+in the CPU tests.
+"""
+import struct
+
+import torch
+
+
+def block_owner(block, world):
+    return block % world
+
+
+def blocks_of(rank, world, num_blocks):
+    return [b for b in range(num_blocks) if block_owner(b, world) == rank]
+
+
+def pack_payload(bwt_t, base_id):
+    """BWT || baseId (uint32 LE) -- the a7 file layout (archon.cpp:895,898) as one tensor."""
+    tail = torch.tensor(list(struct.pack("<I", int(base_id))), dtype=torch.uint8, device=bwt_t.device)
+    return torch.cat([bwt_t.reshape(-1), tail])
+
+
+def unpack_payload(payload_t):
+    p = payload_t.detach().cpu().numpy()
+    return p[:-4], struct.unpack("<I", p[-4:].tobytes())[0]
+
+
+def gather_payloads(dist, payload_t, rank, world, dst=0):
+    """One gather of equal-size payloads to `dst`; returns the list there, None elsewhere."""
+    if world == 1:
+        return [payload_t]
+    out = [torch.empty_like(payload_t) for _ in range(world)] if rank == dst else None
+    dist.gather(payload_t, out, dst=dst)
+    return out
+
+
+def run_sharded(dist, rank, world, blocks, forward_fn, device="cpu"):
+    """Encode `blocks` (list of uint8 tensors, identical on every rank) block-sharded.
+
+    forward_fn(x_t) -> (bwt_t, base_id).  Rounds of `world` blocks: round r handles blocks
+    r*world .. r*world+world-1, rank k encodes block r*world+k (a short last round pads
+    with an empty payload).  Returns on rank 0 the list of (bwt ndarray, base_id) in block
+    order, elsewhere None.
+    """
+    results = [] if rank == 0 else None
+    nb = len(blocks)
+    size = max((int(b.numel()) for b in blocks), default=0)
+    for r0 in range(0, nb, world):
+        b = r0 + rank
+        payload = torch.zeros(size + 8, dtype=torch.uint8, device=device)   # [len:u32][BWT||baseId]...
+        if b < nb:
+            bwt_t, base = forward_fn(blocks[b].to(device))
+            p = pack_payload(bwt_t, base)
+            payload[:4] = torch.tensor(list(struct.pack("<I", int(p.numel()))), dtype=torch.uint8, device=device)
+            payload[4:4 + p.numel()] = p
+        got = gather_payloads(dist, payload, rank, world)
+        if rank == 0:
+            for k in range(world):
+                if r0 + k < nb:
+                    raw = got[k].detach().cpu().numpy()
+                    ln = struct.unpack("<I", raw[:4].tobytes())[0]
+                    results.append(unpack_payload(torch.from_numpy(raw[4:4 + ln].copy())))
+    return results

@@ -3,6 +3,7 @@
 #include "common.hiph"
 #include "util.hiph"
 #include "radix_sort.hiph"
+#include "bucket_sort.hiph"
 #include "forward.hiph"
 #include "inverse.hiph"
 
@@ -25,6 +26,7 @@ void set_error(const char *fmt, ...)
 
 // ------------------------------------------------------------------ contexts
 static constexpr int kMaxDev = 64;
+static constexpr uint32_t kTieListCap = 1u << 20;
 static Ctx *g_ctx[kMaxDev];
 static std::mutex g_ctx_mu;
 
@@ -90,8 +92,8 @@ static size_t forward_arena_bytes(uint32_t n)
     size_t b = 0;
     auto add = [&](size_t bytes) { b += (bytes + 255) & ~size_t(255); };
     add(N + 64);                    // aligned copy of x (when needed)
-    add(8 * N); add(8 * N);         // keyA keyB
-    add(4 * N); add(4 * N);         // valA valB
+    add(8 * N + 64); add(8 * N + 64);   // keyA keyB  (fast path: K,I of pass A / pass B)
+    add(4 * N + 64); add(4 * N + 64);   // valA valB  (fast path: CB of pass A, C of pass B)
     add(4 * (N + 1));               // rank
     add(4 * N);                     // sa (when the caller wants none)
     add(4 * N); add(4 * N); add(4 * N);       // v / gstart, keep, dst
@@ -99,8 +101,83 @@ static size_t forward_arena_bytes(uint32_t n)
     add(4 * scan_temp_words(N));
     add(4 * rs::status_words(n));
     add(4 * 8 * 256); add(4 * 8 * 256);       // ghist, gstart
-    add(4 * 1024);                            // counts, starts, ticket, err, base, totals
+    add(4 * 65536);                           // hist16
+    add(sizeof(bs::Prep));
+    add(sizeof(uint2) * kTieListCap);
+    add(4 * 1024);                            // counts, starts, ticket, err, base, totals, TieCtl
     return b + 4096;
+}
+
+struct FwdBuf {
+    uint8_t *xa;
+    uint64_t *keyA, *keyB;
+    uint32_t *valA, *valB, *rank, *sa_own, *v, *keep, *dst;
+    uint32_t *upos[2], *ug[2], *uitem[2];
+    uint32_t *scan_tmp, *hist16, *small;
+    bs::Prep *prep;
+    uint2 *tie_list;
+    rs::Scratch sc;
+};
+
+// A5 + A7 for whatever the first stage left tied.  On entry: sa[] holds the items in
+// first-stage order, v[i] = i at the first row of every group of equal h-byte keys and 0
+// elsewhere.  Runs scan -> scatter_rank -> doubling rounds -> sa_to_bwt.
+static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, uint32_t n, uint32_t *sa, uint32_t h0,
+                         uint8_t *d_bwt, uint32_t *d_base, archon_hip_stats &st)
+{
+    const uint32_t g256 = div_up(n, 256);
+    ARCHON_TRY(launch_scan<1>(s, B.v, B.v, n, B.scan_tmp, nullptr));
+    hipLaunchKernelGGL(fwd::k_scatter_rank, dim3(g256), dim3(256), 0, s, sa, B.v, n, sa, B.rank, B.keep);
+    uint32_t *d_total = B.small + 600;
+    ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, n, B.scan_tmp, d_total));
+    ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    c->launches += 7;
+    uint32_t m = c->h_mail[0];
+    st.unresolved_initial = m;
+    int cur = 0;
+    if (m) {
+        hipLaunchKernelGGL(fwd::k_compact_first, dim3(g256), dim3(256), 0, s, B.keep, B.dst, B.v, sa, n, B.upos[0], B.ug[0],
+                           B.uitem[0]);
+        ++c->launches;
+    }
+    uint64_t *kT = B.keyA, *kS = B.keyB;
+    uint32_t *vT = B.valA, *vS = B.valB;
+    uint32_t h = h0;
+    while (m) {
+        st.unresolved_total += m;
+        ++st.doubling_rounds;
+        const uint32_t gm = div_up(m, 256);
+        hipLaunchKernelGGL(fwd::k_gather_rank, dim3(gm), dim3(256), 0, s, B.ug[cur], B.uitem[cur], B.rank, h, m, kT, vT);
+        ARCHON_HIP_TRY(hipGetLastError());
+        bool b2 = false;
+        uint32_t passes = 0;
+        ARCHON_TRY(rs::sort_pairs(s, B.sc, kT, vT, kS, vS, m, 0xFFu, &b2, &passes, &c->launches));
+        uint64_t *kR = b2 ? kS : kT;
+        uint32_t *vR = b2 ? vS : vT;
+        hipLaunchKernelGGL(fwd::k_flag_round, dim3(gm), dim3(256), 0, s, kR, B.upos[cur], m, B.v);
+        ARCHON_TRY(launch_scan<1>(s, B.v, B.v, m, B.scan_tmp, nullptr));
+        hipLaunchKernelGGL(fwd::k_round_update, dim3(gm), dim3(256), 0, s, vR, B.upos[cur], B.v, m, sa, B.rank, B.keep);
+        ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, m, B.scan_tmp, d_total));
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        c->launches += 9;
+        const uint32_t m2 = c->h_mail[0];
+        if (m2) {
+            hipLaunchKernelGGL(fwd::k_compact_round, dim3(gm), dim3(256), 0, s, B.keep, B.dst, B.upos[cur], B.v, vR, m,
+                               B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1]);
+            ARCHON_HIP_TRY(hipGetLastError());
+            ++c->launches;
+        }
+        cur ^= 1;
+        m = m2;
+        if (h > n && m) {   // h >= n resolves everything; reaching here means an internal fault
+            set_error("doubling did not converge (m=%u at h=%u)", m, h);
+            return ARCHON_E_INTERNAL;
+        }
+        h = h > 0x40000000u ? 0x80000000u : h * 2;
+    }
+    return ARCHON_OK;
 }
 
 static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n, uint32_t *d_sa_user,
@@ -113,122 +190,159 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     memset(&st, 0, sizeof st);
     st.n = n;
 
-    uint8_t *xa = c->alloc<uint8_t>((size_t)n + 64);
-    uint64_t *keyA = c->alloc<uint64_t>(n), *keyB = c->alloc<uint64_t>(n);
-    uint32_t *valA = c->alloc<uint32_t>(n), *valB = c->alloc<uint32_t>(n);
-    uint32_t *rank = c->alloc<uint32_t>((size_t)n + 1);
-    uint32_t *sa_own = c->alloc<uint32_t>(n);
-    uint32_t *v = c->alloc<uint32_t>(n), *keep = c->alloc<uint32_t>(n), *dst = c->alloc<uint32_t>(n);
-    uint32_t *upos[2], *ug[2], *uitem[2];
+    FwdBuf B;
+    B.xa = c->alloc<uint8_t>((size_t)n + 64);
+    B.keyA = c->alloc<uint64_t>((size_t)n + 8);
+    B.keyB = c->alloc<uint64_t>((size_t)n + 8);
+    B.valA = c->alloc<uint32_t>((size_t)n + 16);
+    B.valB = c->alloc<uint32_t>((size_t)n + 16);
+    B.rank = c->alloc<uint32_t>((size_t)n + 1);
+    B.sa_own = c->alloc<uint32_t>(n);
+    B.v = c->alloc<uint32_t>(n);
+    B.keep = c->alloc<uint32_t>(n);
+    B.dst = c->alloc<uint32_t>(n);
     for (int i = 0; i < 2; ++i) {
-        upos[i] = c->alloc<uint32_t>(n);
-        ug[i] = c->alloc<uint32_t>(n);
-        uitem[i] = c->alloc<uint32_t>(n);
+        B.upos[i] = c->alloc<uint32_t>(n);
+        B.ug[i] = c->alloc<uint32_t>(n);
+        B.uitem[i] = c->alloc<uint32_t>(n);
     }
-    uint32_t *scan_tmp = c->alloc<uint32_t>(scan_temp_words(n));
-    rs::Scratch sc;
-    sc.d_status = c->alloc<uint32_t>(rs::status_words(n));
-    sc.d_ghist = c->alloc<uint32_t>(8 * 256);
-    sc.d_gstart = c->alloc<uint32_t>(8 * 256);
-    uint32_t *small = c->alloc<uint32_t>(1024);
-    if (!small || !sc.d_gstart || !upos[1]) {
+    B.scan_tmp = c->alloc<uint32_t>(scan_temp_words(n));
+    B.sc.d_status = c->alloc<uint32_t>(rs::status_words(n));
+    B.sc.d_ghist = c->alloc<uint32_t>(8 * 256);
+    B.sc.d_gstart = c->alloc<uint32_t>(8 * 256);
+    B.hist16 = c->alloc<uint32_t>(65536);
+    B.prep = c->alloc<bs::Prep>(1);
+    B.tie_list = c->alloc<uint2>(kTieListCap);
+    B.small = c->alloc<uint32_t>(1024);
+    if (!B.small) {
         set_error("arena exhausted");
         return ARCHON_E_NOMEM;
     }
-    uint32_t *d_counts = small, *d_starts = small + 256, *d_total = small + 600;
-    sc.d_ticket = small + 601;
-    sc.d_err = small + 602;
+    uint32_t *small = B.small;
+    uint32_t *d_counts = small, *d_starts = small + 256;
+    B.sc.d_ticket = small + 601;
+    B.sc.d_err = small + 602;
     uint32_t *d_base = small + 603;
-    sc.h_mail = c->h_mail;
+    bs::TieCtl *d_ctl = reinterpret_cast<bs::TieCtl *>(small + 640);
+    B.sc.h_mail = c->h_mail;
     ARCHON_HIP_TRY(hipMemsetAsync(small, 0, 1024 * sizeof(uint32_t), s));
 
     const uint8_t *d_x = d_x_in;
     if ((uintptr_t)d_x_in & 15) {   // kernels want 16-byte aligned text
-        ARCHON_HIP_TRY(hipMemcpyAsync(xa, d_x_in, n, hipMemcpyDeviceToDevice, s));
-        d_x = xa;
+        ARCHON_HIP_TRY(hipMemcpyAsync(B.xa, d_x_in, n, hipMemcpyDeviceToDevice, s));
+        d_x = B.xa;
     }
-    uint32_t *sa = d_sa_user ? d_sa_user : sa_own;
+    uint32_t *sa = d_sa_user ? d_sa_user : B.sa_own;
+    const uint32_t g256 = div_up(n, 256);
 
     StageTimer tm(s);
+    StageTimer pt(s);
     const int e0 = tm.mark();
 
-    // A2: bucket setup
-    ARCHON_TRY(launch_hist256(s, d_x, n, d_counts, n));
-    hipLaunchKernelGGL(k_scan257, dim3(1), dim3(64), 0, s, d_counts, d_starts);
-    c->launches += 2;
-    const int e1 = tm.mark();
-
-    // A4: first-stage LSB radix bucketing on 7 key bytes
-    const uint32_t g256 = div_up(n, 256);
-    hipLaunchKernelGGL(fwd::k_init_keys, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, keyA, valA);
-    ARCHON_HIP_TRY(hipGetLastError());
-    ++c->launches;
-    bool in_b = false;
-    StageTimer pt(s);
-    ARCHON_TRY(rs::sort_pairs(s, sc, keyA, valA, keyB, valB, n, 0xFEu, &in_b, &st.radix_passes, &c->launches, &pt));
-    uint64_t *kS = in_b ? keyB : keyA, *kT = in_b ? keyA : keyB;
-    uint32_t *vS = in_b ? valB : valA, *vT = in_b ? valA : valB;
-    const int e2 = tm.mark();
-
-    // A5: boundaries -> group starts -> ranks -> working set
-    hipLaunchKernelGGL(fwd::k_flag_boundaries, dim3(g256), dim3(256), 0, s, kS, n, v);
-    ARCHON_TRY(launch_scan<1>(s, v, v, n, scan_tmp, nullptr));
-    hipLaunchKernelGGL(fwd::k_scatter_rank, dim3(g256), dim3(256), 0, s, vS, v, n, sa, rank, keep);
-    ARCHON_TRY(launch_scan<0>(s, keep, dst, n, scan_tmp, d_total));
-    ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
-    c->launches += 8;
-    uint32_t m = c->h_mail[0];
-    st.unresolved_initial = m;
-    int cur = 0;
-    if (m) {
-        hipLaunchKernelGGL(fwd::k_compact_first, dim3(g256), dim3(256), 0, s, keep, dst, v, vS, n, upos[0], ug[0], uitem[0]);
-        ++c->launches;
-    }
-
-    // prefix doubling over the unresolved items
-    uint32_t h = fwd::kKeyBytes;
-    while (m) {
-        st.unresolved_total += m;
-        ++st.doubling_rounds;
-        const uint32_t gm = div_up(m, 256);
-        hipLaunchKernelGGL(fwd::k_gather_rank, dim3(gm), dim3(256), 0, s, ug[cur], uitem[cur], rank, h, m, kT, vT);
+    // A2 / bucket setup: the two-byte count (a4 compute(), archon.c:146-161) and its scans
+    ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, 65536 * sizeof(uint32_t), s));
+    {
+        uint32_t per_block = (div_up(n, kNumCU) + 3u) & ~3u;
+        if (per_block < 4096) per_block = 4096;
+        const uint32_t ranges = div_up(n, per_block);
+        hipLaunchKernelGGL(bs::k_hist16, dim3(ranges, 2), dim3(bs::kH16Block), 0, s, d_x, n, B.hist16, per_block);
+        hipLaunchKernelGGL(bs::k_prep16, dim3(1), dim3(1024), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
         ARCHON_HIP_TRY(hipGetLastError());
-        bool b2 = false;
-        uint32_t passes = 0;
-        ARCHON_TRY(rs::sort_pairs(s, sc, kT, vT, kS, vS, m, 0xFFu, &b2, &passes, &c->launches));
-        uint64_t *kR = b2 ? kS : kT;
-        uint32_t *vR = b2 ? vS : vT;
-        hipLaunchKernelGGL(fwd::k_flag_round, dim3(gm), dim3(256), 0, s, kR, upos[cur], m, v);
-        ARCHON_TRY(launch_scan<1>(s, v, v, m, scan_tmp, nullptr));
-        hipLaunchKernelGGL(fwd::k_round_update, dim3(gm), dim3(256), 0, s, vR, upos[cur], v, m, sa, rank, keep);
-        ARCHON_TRY(launch_scan<0>(s, keep, dst, m, scan_tmp, d_total));
-        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        c->launches += 2;
+    }
+    ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, &B.prep->big_items, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    const int e1 = tm.mark();
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t big_items = c->h_mail[0];
+    int path = (uint64_t)big_items * 2 <= n ? 1 : 0;
+    if (const char *f = getenv("ARCHON_FORCE_PATH")) path = atoi(f) ? 1 : 0;
+    st.path = (uint32_t)path;
+
+    int e2 = e1, e3 = e1, e4 = e1;
+    bool need_general = true;
+    uint32_t h0 = fwd::kKeyBytes;
+    if (path == 1) {
+        // ---- streaming first stage: two LSB passes + in-LDS bucket sorts ----
+        uint32_t *A_K = reinterpret_cast<uint32_t *>(B.keyA), *A_I = A_K + n + 8;
+        uint32_t *B_K = reinterpret_cast<uint32_t *>(B.keyB), *B_I = B_K + n + 8;
+        uint16_t *A_CB = reinterpret_cast<uint16_t *>(B.valA);
+        uint8_t *B_C = reinterpret_cast<uint8_t *>(B.valB);
+        const uint32_t ntiles = div_up(n, bs::kTile);
+        bs::TieCtl h_ctl;
+        memset(&h_ctl, 0, sizeof h_ctl);
+        h_ctl.min_depth = 5;
+        h_ctl.base_id = 0xFFFFFFFFu;
+        h_ctl.list_cap = kTieListCap;
+        ARCHON_HIP_TRY(hipMemcpyAsync(d_ctl, &h_ctl, sizeof h_ctl, hipMemcpyHostToDevice, s));
+        ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_status, 0, (size_t)ntiles * 256 * sizeof(uint32_t), s));
+        ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
+        pt.mark();
+        hipLaunchKernelGGL(bs::k_pass_text, dim3(ntiles), dim3(bs::kBlock), 0, s, d_x, n, A_K, A_I, A_CB, B.prep->startA,
+                           B.sc.d_status, B.sc.d_ticket, B.sc.d_err);
+        pt.mark();
+        ARCHON_HIP_TRY(hipGetLastError());
+        ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_status, 0, (size_t)ntiles * 256 * sizeof(uint32_t), s));
+        ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
+        pt.mark();
+        hipLaunchKernelGGL(bs::k_pass_rec, dim3(ntiles), dim3(bs::kBlock), 0, s, A_K, A_I, A_CB, n, B_K, B_I, B_C,
+                           B.prep->startB, B.sc.d_status, B.sc.d_ticket, B.sc.d_err);
+        pt.mark();
+        ARCHON_HIP_TRY(hipGetLastError());
+        e2 = tm.mark();
+        hipLaunchKernelGGL(bs::k_local_sort, dim3(65536), dim3(bs::kLsBlock), 0, s, B_K, B_I, B_C, B.prep->start16, n, sa,
+                           d_bwt, d_ctl, B.tie_list);
+        ARCHON_HIP_TRY(hipGetLastError());
+        const int e2b = tm.mark();
+        hipLaunchKernelGGL(bs::k_resolve_ties, dim3(div_up(kTieListCap, 256)), dim3(256), 0, s, d_x, n, B.tie_list, d_ctl,
+                           sa, d_bwt, 5u, 64u);
+        ARCHON_HIP_TRY(hipGetLastError());
+        c->launches += 4;
+        st.radix_passes = 2;
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_ctl, sizeof(bs::TieCtl), hipMemcpyDeviceToHost, s));
+        e3 = tm.mark();
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
-        c->launches += 9;
-        const uint32_t m2 = c->h_mail[0];
-        if (m2) {
-            hipLaunchKernelGGL(fwd::k_compact_round, dim3(gm), dim3(256), 0, s, keep, dst, upos[cur], v, vR, m,
-                               upos[cur ^ 1], ug[cur ^ 1], uitem[cur ^ 1]);
-            ARCHON_HIP_TRY(hipGetLastError());
+        memcpy(&h_ctl, c->h_mail, sizeof h_ctl);
+        st.tie_groups = h_ctl.tie_groups;
+        st.tie_items = h_ctl.tie_items;
+        st.ms_local_sort = tm.ms(e2, e2b);
+        st.ms_resolve = tm.ms(e2b, e3);
+        if (h_ctl.unresolved == 0 && h_ctl.tie_groups <= kTieListCap) {
+            need_general = false;
+            if (h_ctl.base_id >= n) { set_error("primary index not found"); return ARCHON_E_INTERNAL; }
+            ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, &d_ctl->base_id, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        } else {
+            h0 = h_ctl.min_depth < 5 ? h_ctl.min_depth : 5;
+            hipLaunchKernelGGL(bs::k_flags_from_sa, dim3(g256), dim3(256), 0, s, sa, n, B.v);
             ++c->launches;
         }
-        cur ^= 1;
-        m = m2;
-        if (h > n) {   // h >= n resolves everything; reaching here means an internal fault
-            if (m) { set_error("doubling did not converge (m=%u at h=%u)", m, h); return ARCHON_E_INTERNAL; }
-        }
-        h = h > 0x40000000u ? 0x80000000u : h * 2;
+        e4 = e3;
+    } else {
+        // ---- first stage for heavily skewed blocks: 7 LSB passes on packed 7-byte keys ----
+        hipLaunchKernelGGL(fwd::k_init_keys, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, B.keyA, B.valA);
+        ARCHON_HIP_TRY(hipGetLastError());
+        ++c->launches;
+        bool in_b = false;
+        ARCHON_TRY(rs::sort_pairs(s, B.sc, B.keyA, B.valA, B.keyB, B.valB, n, 0xFEu, &in_b, &st.radix_passes, &c->launches, &pt));
+        uint64_t *kS = in_b ? B.keyB : B.keyA;
+        uint32_t *vS = in_b ? B.valB : B.valA;
+        e2 = tm.mark();
+        hipLaunchKernelGGL(fwd::k_flag_boundaries, dim3(g256), dim3(256), 0, s, kS, n, B.v);
+        ARCHON_HIP_TRY(hipMemcpyAsync(sa, vS, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        c->launches += 2;
+        e3 = e2;
     }
-    const int e3 = tm.mark();
 
-    // A7: SA -> BWT + primary index
-    hipLaunchKernelGGL(fwd::k_sa_to_bwt, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, sa, n, d_bwt, d_base);
-    ARCHON_HIP_TRY(hipGetLastError());
-    ++c->launches;
-    ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, d_base, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-    const int e4 = tm.mark();
-    ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, sc.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (need_general) {
+        ARCHON_TRY(general_stage(c, s, B, d_x, n, sa, h0, d_bwt, d_base, st));
+        e4 = tm.mark();
+        // A7: SA -> BWT + primary index
+        hipLaunchKernelGGL(fwd::k_sa_to_bwt, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, sa, n, d_bwt, d_base);
+        ARCHON_HIP_TRY(hipGetLastError());
+        ++c->launches;
+        ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, d_base, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    }
+    const int e5 = tm.mark();
+    ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, B.sc.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     ARCHON_HIP_TRY(hipStreamSynchronize(s));
     if (c->h_mail[0]) {
         set_error("device consistency flag 0x%x (look-back spin bound)", c->h_mail[0]);
@@ -236,14 +350,15 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     }
     st.ms_hist = tm.ms(e0, e1);
     st.ms_sort = tm.ms(e1, e2);
-    st.ms_doubling = tm.ms(e2, e3);
-    st.ms_bwt = tm.ms(e3, e4);
-    st.ms_total = tm.ms(e0, e4);
+    st.ms_doubling = need_general ? tm.ms(e3, e4) : 0.f;
+    st.ms_bwt = need_general ? tm.ms(e4, e5) : 0.f;
+    st.ms_total = tm.ms(e0, e5);
     st.kernel_launches = c->launches;
     for (int i = 0; i + 1 < pt.n; i += 2) {
         st.ms_radix_pass_sum += pt.ms(i, i + 1);
         ++st.radix_pass_timed;
     }
+    (void)d_counts; (void)d_starts;
     return ARCHON_OK;
 }
 

@@ -37,7 +37,8 @@ class Stats(ctypes.Structure):
         ("ms_doubling", ctypes.c_float), ("ms_bwt", ctypes.c_float), ("ms_lf_build", ctypes.c_float),
         ("ms_lf_walk", ctypes.c_float), ("_pad1", ctypes.c_uint32),
         ("walk_chains", ctypes.c_uint64), ("kernel_launches", ctypes.c_uint32), ("radix_pass_timed", ctypes.c_uint32),
-        ("ms_radix_pass_sum", ctypes.c_float), ("_pad2", ctypes.c_float),
+        ("ms_radix_pass_sum", ctypes.c_float), ("ms_local_sort", ctypes.c_float), ("ms_resolve", ctypes.c_float),
+        ("path", ctypes.c_uint32), ("tie_groups", ctypes.c_uint32), ("tie_items", ctypes.c_uint32),
     ]
 
     def asdict(self):

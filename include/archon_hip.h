@@ -127,8 +127,12 @@ typedef struct archon_hip_stats {
     uint64_t walk_chains;        /* inverse: number of sub-chains walked in parallel */
     uint32_t kernel_launches;    /* launches issued by the call */
     uint32_t radix_pass_timed;   /* first-stage radix passes bracketed by their own HIP events */
-    float ms_radix_pass_sum;     /* device time inside those passes (k_scatter only) */
-    float ms_reserved;
+    float ms_radix_pass_sum;     /* device time inside those passes (pass kernels only) */
+    float ms_local_sort;         /* streaming path: in-LDS bucket sorts (k_local_sort) */
+    float ms_resolve;            /* streaming path: k_resolve_ties */
+    uint32_t path;               /* 1 = streaming first stage (2 passes + local sort), 0 = 7-pass LSB */
+    uint32_t tie_groups;         /* groups still tied after 5 key bytes */
+    uint32_t tie_items;          /* rows flagged as tied by k_local_sort */
 } archon_hip_stats;
 
 int archon_hip_get_stats(int dev, archon_hip_stats *out);
