@@ -242,7 +242,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // A2 / bucket setup: the two-byte count (a4 compute(), archon.c:146-161) and its scans
     ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, 65536 * sizeof(uint32_t), s));
     {
-        uint32_t per_block = (div_up(n, kNumCU) + 3u) & ~3u;
+        uint32_t per_block = (div_up(n, kNumCU) + 15u) & ~15u;
         if (per_block < 4096) per_block = 4096;
         const uint32_t ranges = div_up(n, per_block);
         hipLaunchKernelGGL(bs::k_hist16, dim3(ranges, 2), dim3(bs::kH16Block), 0, s, d_x, n, B.hist16, per_block);
@@ -258,6 +258,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     if (const char *f = getenv("ARCHON_FORCE_PATH")) path = atoi(f) ? 1 : 0;
     st.path = (uint32_t)path;
 
+    const uint32_t dbg = getenv("ARCHON_DEBUG") ? (uint32_t)atoi(getenv("ARCHON_DEBUG")) : 0u;   // timing experiments only
     int e2 = e1, e3 = e1, e4 = e1;
     bool need_general = true;
     uint32_t h0 = fwd::kKeyBytes;
@@ -274,20 +275,34 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         h_ctl.base_id = 0xFFFFFFFFu;
         h_ctl.list_cap = kTieListCap;
         ARCHON_HIP_TRY(hipMemcpyAsync(d_ctl, &h_ctl, sizeof h_ctl, hipMemcpyHostToDevice, s));
-        ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_status, 0, (size_t)ntiles * 256 * sizeof(uint32_t), s));
-        ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
+        // R contiguous tile ranges, one persistent workgroup each (3 per CU)
+        const int geo = getenv("ARCHON_PASS_GEOMETRY") ? atoi(getenv("ARCHON_PASS_GEOMETRY")) : 0;   // 0: 512x16, 1: 1024x8
+        uint32_t R = (uint32_t)kNumCU * (geo == 1 ? 1 : 2);   // = co-resident workgroups
+        if (const char *e = getenv("ARCHON_PASS_RANGES")) R = (uint32_t)atoi(e);
+        if (R > (uint32_t)bs::kMaxRanges) R = bs::kMaxRanges;
+        if (R > ntiles) R = ntiles;
+        const uint32_t tpr = div_up(ntiles, R);
+        R = div_up(ntiles, tpr);
+        uint32_t *rhist = B.sc.d_status;            // [R][256], reused by both passes
+        hipLaunchKernelGGL(bs::k_range_hist_text, dim3(R), dim3(256), 0, s, d_x, n, tpr, rhist);
         pt.mark();
-        hipLaunchKernelGGL(bs::k_pass_text, dim3(ntiles), dim3(bs::kBlock), 0, s, d_x, n, A_K, A_I, A_CB, B.prep->startA,
-                           B.sc.d_status, B.sc.d_ticket, B.sc.d_err);
+        if (geo == 1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 8>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_CB, B.prep->startA, rhist, dbg);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 16>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_CB, B.prep->startA, rhist, dbg);
         pt.mark();
         ARCHON_HIP_TRY(hipGetLastError());
-        ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_status, 0, (size_t)ntiles * 256 * sizeof(uint32_t), s));
-        ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(bs::k_range_hist_cb, dim3(R), dim3(256), 0, s, A_CB, n, tpr, rhist);
         pt.mark();
-        hipLaunchKernelGGL(bs::k_pass_rec, dim3(ntiles), dim3(bs::kBlock), 0, s, A_K, A_I, A_CB, n, B_K, B_I, B_C,
-                           B.prep->startB, B.sc.d_status, B.sc.d_ticket, B.sc.d_err);
+        if (geo == 1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 8>), dim3(R), dim3(1024), 0, s, A_K, A_I, A_CB, n, tpr, B_K, B_I, B_C,
+                               B.prep->startB, rhist, dbg);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16>), dim3(R), dim3(512), 0, s, A_K, A_I, A_CB, n, tpr, B_K, B_I, B_C,
+                               B.prep->startB, rhist, dbg);
         pt.mark();
         ARCHON_HIP_TRY(hipGetLastError());
+        c->launches += 2;
         e2 = tm.mark();
         hipLaunchKernelGGL(bs::k_local_sort, dim3(65536), dim3(bs::kLsBlock), 0, s, B_K, B_I, B_C, B.prep->start16, n, sa,
                            d_bwt, d_ctl, B.tie_list);
@@ -306,7 +321,9 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         st.tie_items = h_ctl.tie_items;
         st.ms_local_sort = tm.ms(e2, e2b);
         st.ms_resolve = tm.ms(e2b, e3);
-        if (h_ctl.unresolved == 0 && h_ctl.tie_groups <= kTieListCap) {
+        if (dbg) {
+            need_general = false;   // timing experiment: outputs are garbage
+        } else if (h_ctl.unresolved == 0 && h_ctl.tie_groups <= kTieListCap) {
             need_general = false;
             if (h_ctl.base_id >= n) { set_error("primary index not found"); return ARCHON_E_INTERNAL; }
             ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, &d_ctl->base_id, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
