@@ -162,10 +162,17 @@ def main():
         ms_per_step = dt * 1e3 / args.steps
         total_bytes = float(n) * world * args.steps
         value = total_bytes / 1e6 / dt
-        npass = max(1, sum(pass_cnt))
-        t_pass_ms = sum(pass_ms) / npass
-        achieved = B_RADIX_PASS * n / (t_pass_ms * 1e-3) / 1e9 if t_pass_ms > 0 else 0.0
         last = stage[-1]
+        if last["path"] == 1:     # streaming first stage: the dominant kernel is LSB pass B (bs::k_pass_rec)
+            t_pass_ms = float(np.mean([s["ms_pass_rec"] for s in stage]))
+            kname = "bs::k_pass_rec (LSB radix pass B over %d items: stable 256-way bucketing of key+index+symbol records)" % n
+            per_step = 1
+        else:
+            npass = max(1, sum(pass_cnt))
+            t_pass_ms = sum(pass_ms) / npass
+            kname = "rs::k_scatter (one LSB radix pass over %d (key,index) pairs)" % n
+            per_step = last["radix_pass_timed"]
+        achieved = B_RADIX_PASS * n / (t_pass_ms * 1e-3) / 1e9 if t_pass_ms > 0 else 0.0
         dev_ms = float(np.mean([s["ms_total"] for s in stage]))
         line = {
             "metric": "forward-BWT MB/s on 256 MB block (SA bit-exact vs a7 order)",
@@ -191,22 +198,26 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "rs::k_scatter (one LSB radix pass over %d items)" % n,
+                "kernel": kname,
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None,
                 "launch_ms": round(t_pass_ms, 4),
-                "launches_per_step": last["radix_pass_timed"],
+                "launches_per_step": per_step,
                 "algorithmic_bytes_per_launch": B_RADIX_PASS * n,
             },
             "pipeline": {
                 "device_ms_per_block": round(dev_ms, 3),
                 "algorithmic_bytes_per_input_byte": B_FWD_CFG2,
                 "frac_of_hbm_roofline": round(B_FWD_CFG2 * n / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dev_ms > 0 else None,
+                "path": "streaming (hist16, 2 LSB passes, in-LDS bucket sort)" if last["path"] == 1 else "7 LSB passes + doubling",
                 "ms_hist": round(last["ms_hist"], 3), "ms_sort": round(last["ms_sort"], 3),
+                "ms_pass_text": round(last["ms_pass_text"], 3), "ms_pass_rec": round(last["ms_pass_rec"], 3),
+                "ms_local_sort": round(last["ms_local_sort"], 3), "ms_resolve": round(last["ms_resolve"], 3),
                 "ms_doubling": round(last["ms_doubling"], 3), "ms_bwt": round(last["ms_bwt"], 3),
+                "tie_groups_after_5_bytes": last["tie_groups"],
                 "radix_passes": last["radix_passes"], "doubling_rounds": last["doubling_rounds"],
                 "unresolved_initial": last["unresolved_initial"], "kernel_launches": last["kernel_launches"],
             },

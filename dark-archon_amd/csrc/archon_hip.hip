@@ -266,8 +266,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         // ---- streaming first stage: two LSB passes + in-LDS bucket sorts ----
         uint32_t *A_K = reinterpret_cast<uint32_t *>(B.keyA), *A_I = A_K + n + 8;
         uint32_t *B_K = reinterpret_cast<uint32_t *>(B.keyB), *B_I = B_K + n + 8;
-        uint16_t *A_CB = reinterpret_cast<uint16_t *>(B.valA);
-        uint8_t *B_C = reinterpret_cast<uint8_t *>(B.valB);
+        uint8_t *A_B1 = reinterpret_cast<uint8_t *>(B.valA);
         const uint32_t ntiles = div_up(n, bs::kTile);
         bs::TieCtl h_ctl;
         memset(&h_ctl, 0, sizeof h_ctl);
@@ -284,27 +283,31 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         const uint32_t tpr = div_up(ntiles, R);
         R = div_up(ntiles, tpr);
         uint32_t *rhist = B.sc.d_status;            // [R][256], reused by both passes
-        hipLaunchKernelGGL(bs::k_range_hist_text, dim3(R), dim3(256), 0, s, d_x, n, tpr, rhist);
+        hipLaunchKernelGGL(bs::k_range_hist_text, dim3(R), dim3(256), 0, s, d_x, n, tpr, rhist, 1u);
         pt.mark();
         if (geo == 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 8>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_CB, B.prep->startA, rhist, dbg);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 8>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 16>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_CB, B.prep->startA, rhist, dbg);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 16>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);
         pt.mark();
         ARCHON_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(bs::k_range_hist_cb, dim3(R), dim3(256), 0, s, A_CB, n, tpr, rhist);
+        hipLaunchKernelGGL(bs::k_range_hist_text, dim3(R), dim3(256), 0, s, A_B1, n, tpr, rhist, 0u);
         pt.mark();
-        if (geo == 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 8>), dim3(R), dim3(1024), 0, s, A_K, A_I, A_CB, n, tpr, B_K, B_I, B_C,
-                               B.prep->startB, rhist, dbg);
+        unsigned long long *d_stamps = reinterpret_cast<unsigned long long *>(small + 800);
+        if (dbg & 4u)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, true>), dim3(R), dim3(512), 0, s, A_K, A_I, A_B1, n, tpr, B_K, B_I,
+                               B.prep->startB, rhist, dbg & 1u, d_stamps);
+        else if (geo == 1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 8, false>), dim3(R), dim3(1024), 0, s, A_K, A_I, A_B1, n, tpr, B_K, B_I,
+                               B.prep->startB, rhist, dbg, d_stamps);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16>), dim3(R), dim3(512), 0, s, A_K, A_I, A_CB, n, tpr, B_K, B_I, B_C,
-                               B.prep->startB, rhist, dbg);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, false>), dim3(R), dim3(512), 0, s, A_K, A_I, A_B1, n, tpr, B_K, B_I,
+                               B.prep->startB, rhist, dbg, d_stamps);
         pt.mark();
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 2;
         e2 = tm.mark();
-        hipLaunchKernelGGL(bs::k_local_sort, dim3(65536), dim3(bs::kLsBlock), 0, s, B_K, B_I, B_C, B.prep->start16, n, sa,
+        hipLaunchKernelGGL(bs::k_local_sort, dim3(65536), dim3(bs::kLsBlock), 0, s, B_K, B_I, B.prep->start16, n, sa,
                            d_bwt, d_ctl, B.tie_list);
         ARCHON_HIP_TRY(hipGetLastError());
         const int e2b = tm.mark();
@@ -321,7 +324,13 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         st.tie_items = h_ctl.tie_items;
         st.ms_local_sort = tm.ms(e2, e2b);
         st.ms_resolve = tm.ms(e2b, e3);
-        if (dbg) {
+        if (dbg & 4u) {
+            unsigned long long hs[8];
+            ARCHON_HIP_TRY(hipMemcpy(hs, small + 800, sizeof hs, hipMemcpyDeviceToHost));
+            fprintf(stderr, "pass B stamps (cycles, workgroup 0): load-issue %llu | load-wait %llu | rank %llu | layout %llu | emitK %llu | emitI %llu | - %llu | advance %llu\n",
+                    hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7]);
+        }
+        if (dbg & 1u) {
             need_general = false;   // timing experiment: outputs are garbage
         } else if (h_ctl.unresolved == 0 && h_ctl.tie_groups <= kTieListCap) {
             need_general = false;
@@ -374,6 +383,10 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     for (int i = 0; i + 1 < pt.n; i += 2) {
         st.ms_radix_pass_sum += pt.ms(i, i + 1);
         ++st.radix_pass_timed;
+    }
+    if (path == 1 && pt.n >= 4) {
+        st.ms_pass_text = pt.ms(0, 1);
+        st.ms_pass_rec = pt.ms(2, 3);
     }
     (void)d_counts; (void)d_starts;
     return ARCHON_OK;

@@ -39,6 +39,7 @@ class Stats(ctypes.Structure):
         ("walk_chains", ctypes.c_uint64), ("kernel_launches", ctypes.c_uint32), ("radix_pass_timed", ctypes.c_uint32),
         ("ms_radix_pass_sum", ctypes.c_float), ("ms_local_sort", ctypes.c_float), ("ms_resolve", ctypes.c_float),
         ("path", ctypes.c_uint32), ("tie_groups", ctypes.c_uint32), ("tie_items", ctypes.c_uint32),
+        ("ms_pass_text", ctypes.c_float), ("ms_pass_rec", ctypes.c_float),
     ]
 
     def asdict(self):

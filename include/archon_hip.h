@@ -133,6 +133,8 @@ typedef struct archon_hip_stats {
     uint32_t path;               /* 1 = streaming first stage (2 passes + local sort), 0 = 7-pass LSB */
     uint32_t tie_groups;         /* groups still tied after 5 key bytes */
     uint32_t tie_items;          /* rows flagged as tied by k_local_sort */
+    float ms_pass_text;          /* streaming path: LSB pass A (k_pass_text), its own HIP events */
+    float ms_pass_rec;           /* streaming path: LSB pass B (k_pass_rec), its own HIP events */
 } archon_hip_stats;
 
 int archon_hip_get_stats(int dev, archon_hip_stats *out);
