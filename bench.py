@@ -12,9 +12,11 @@ are gathered to rank 0 over RCCL (the path's one exchange step).
 Blocks are independent, per-GPU work is fixed: "scaling": "weak".
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline      the dominant kernel (one LSB radix pass, rs::k_scatter): algorithmic
-                bytes per launch (9 B x N) / its mean launch time, taken
-                live from HIP events recorded around each launch on the kernel's stream
+  roofline      the dominant kernel (LSB radix pass B, bs::k_pass_rec): algorithmic bytes per
+                launch (9 B x N) / its mean launch time, taken live from HIP
+                events recorded around each launch on the stream the library launches on;
+                "traffic" = HBM bytes per launch from the committed rocprofv3 PMC passes
+                (profiles/pmc_traffic.json), null when no matching measurement is committed
   cpu_baseline  the reference a7 (oracle/_ref/a7ref, built from /root/reference by
                 oracle/Makefile; kind "reference") or, when that binary is absent, the
                 repo's CPU oracle (kind "port"), single thread, on a bounded sample of
@@ -75,6 +77,18 @@ def cpu_baseline(block_bytes):
             "host_cores": os.cpu_count()}
 
 
+def pmc_traffic(path, n, shape):
+    """HBM bytes per launch of the dominant kernel, from the committed PMC summary (same command,
+    separate --pmc passes, gfx950 FETCH_SIZE correction applied as documented there)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        key = "path%d_%s_%d" % (path, shape, n)
+        return t[key]["hbm_bytes_per_launch"] if key in t else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,7 +109,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -203,7 +217,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic(last["path"], n, args.shape),
                 "launch_ms": round(t_pass_ms, 4),
                 "launches_per_step": per_step,
                 "algorithmic_bytes_per_launch": B_RADIX_PASS * n,

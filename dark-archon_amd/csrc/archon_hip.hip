@@ -307,8 +307,12 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 2;
         e2 = tm.mark();
-        hipLaunchKernelGGL(bs::k_local_sort, dim3(65536), dim3(bs::kLsBlock), 0, s, B_K, B_I, B.prep->start16, n, sa,
-                           d_bwt, d_ctl, B.tie_list);
+        if (dbg & 8u)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_local_sort<true>), dim3(65536), dim3(bs::kLsBlock), 0, s, B_K, B_I, B.prep->start16, n, sa,
+                               d_bwt, d_ctl, B.tie_list, reinterpret_cast<unsigned long long *>(small + 820));
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_local_sort<false>), dim3(65536), dim3(bs::kLsBlock), 0, s, B_K, B_I, B.prep->start16, n, sa,
+                               d_bwt, d_ctl, B.tie_list, reinterpret_cast<unsigned long long *>(small + 820));
         ARCHON_HIP_TRY(hipGetLastError());
         const int e2b = tm.mark();
         hipLaunchKernelGGL(bs::k_resolve_ties, dim3(div_up(kTieListCap, 256)), dim3(256), 0, s, d_x, n, B.tie_list, d_ctl,
@@ -328,6 +332,12 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             unsigned long long hs[8];
             ARCHON_HIP_TRY(hipMemcpy(hs, small + 800, sizeof hs, hipMemcpyDeviceToHost));
             fprintf(stderr, "pass B stamps (cycles, workgroup 0): load-issue %llu | load-wait %llu | rank %llu | layout %llu | emitK %llu | emitI %llu | - %llu | advance %llu\n",
+                    hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7]);
+        }
+        if (dbg & 8u) {
+            unsigned long long hs[8];
+            ARCHON_HIP_TRY(hipMemcpy(hs, small + 820, sizeof hs, hipMemcpyDeviceToHost));
+            fprintf(stderr, "local sort stamps (cycles, bucket 30000): loads %llu | barrier %llu | atomics %llu | scan %llu | scatterK %llu | rank-loops %llu | write-IC %llu | output %llu\n",
                     hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7]);
         }
         if (dbg & 1u) {

@@ -114,3 +114,56 @@ def test_errors(archon):
     bp = ctypes.cast(ctypes.byref(base), ctypes.c_void_p)
     assert L.archon_hip_forward(ctypes.c_void_p(x.ctypes.data), 0, None, ctypes.c_void_p(b.ctypes.data), bp, 0) == archon.E_ARG
     assert L.archon_hip_forward(ctypes.c_void_p(x.ctypes.data), 4, None, ctypes.c_void_p(b.ctypes.data), bp, 99) == archon.E_NODEVICE
+
+
+def test_full_block_properties(archon):
+    """BASELINE size (256 MiB uniform random, config 2): size-independent properties only --
+    LF-consistency of the SA on the device, BWT is a permutation of the block, and the
+    encode -> decode round trip; everything through the C ABI with device-resident buffers."""
+    import torch
+    n = 256 << 20
+    x = S.gen_random(n)
+    x_t = torch.from_numpy(x).cuda()
+    sa_t = torch.empty(n, dtype=torch.int32, device="cuda")
+    bwt_t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    base_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+    archon.forward_dev(x_t, sa_t, bwt_t, base_t)
+    st = archon.stats()
+    assert st["path"] == 1 and st["doubling_rounds"] == 0
+    assert archon.validate_dev(x_t, sa_t)
+    base = int(base_t.item())
+    assert int(sa_t[base].item()) == n
+    assert torch.equal(torch.bincount(bwt_t.int(), minlength=256), torch.bincount(x_t.int(), minlength=256))
+    out_t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    archon.inverse_dev(bwt_t, base, out_t)
+    assert torch.equal(out_t, x_t)
+    # the 7-pass route (taken by heavily skewed blocks) must produce the same SA on the same bytes
+    import os
+    os.environ["ARCHON_FORCE_PATH"] = "0"
+    try:
+        sa2_t = torch.empty(n // 8, dtype=torch.int32, device="cuda")
+        bwt2_t = torch.empty(n // 8, dtype=torch.uint8, device="cuda")
+        archon.forward_dev(x_t[: n // 8], sa2_t, bwt2_t, base_t)
+        assert archon.stats()["path"] == 0
+        os.environ["ARCHON_FORCE_PATH"] = "1"
+        sa3_t = torch.empty(n // 8, dtype=torch.int32, device="cuda")
+        archon.forward_dev(x_t[: n // 8], sa3_t, bwt2_t, base_t)
+        assert torch.equal(sa2_t, sa3_t)
+    finally:
+        del os.environ["ARCHON_FORCE_PATH"]
+
+
+@pytest.mark.parametrize("shape", ["dna", "a", "ab", "motif", "text"])
+def test_large_shapes_lf_consistent(archon, shape):
+    """64 MiB blocks of the skewed shapes (configs 3-5 at reduced size): LF-consistency + round trip."""
+    import torch
+    n = 64 << 20
+    x_t = torch.from_numpy(S.gen_shape(shape, n)).cuda()
+    sa_t = torch.empty(n, dtype=torch.int32, device="cuda")
+    bwt_t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    base_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+    archon.forward_dev(x_t, sa_t, bwt_t, base_t)
+    assert archon.validate_dev(x_t, sa_t)
+    out_t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    archon.inverse_dev(bwt_t, int(base_t.item()), out_t)
+    assert torch.equal(out_t, x_t)
