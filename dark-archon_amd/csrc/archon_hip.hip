@@ -239,13 +239,22 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     StageTimer pt(s);
     const int e0 = tm.mark();
 
-    // A2 / bucket setup: the two-byte count (a4 compute(), archon.c:146-161) and its scans
+    // A2 / bucket setup: the two-byte count (a4 compute(), archon.c:146-161) and its scans.  The count
+    // runs over the tile ranges of LSB pass A (R contiguous ranges, one persistent workgroup each), so
+    // the same sweep also delivers that pass's per-range digit table.
+    const int geo = getenv("ARCHON_PASS_GEOMETRY") ? atoi(getenv("ARCHON_PASS_GEOMETRY")) : 0;   // 0: 512x16, 1: 1024x8
+    const uint32_t ntiles = div_up(n, bs::kTile);
+    uint32_t R = (uint32_t)kNumCU * (geo == 1 ? 1 : 2);   // = co-resident workgroups
+    if (const char *e = getenv("ARCHON_PASS_RANGES")) R = (uint32_t)atoi(e);
+    if (R > (uint32_t)bs::kMaxRanges) R = bs::kMaxRanges;
+    if (R > ntiles) R = ntiles;
+    const uint32_t tpr = div_up(ntiles, R);
+    R = div_up(ntiles, tpr);
+    uint32_t *rhist = B.sc.d_status;            // [R][256], reused by both passes
     ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, 65536 * sizeof(uint32_t), s));
+    ARCHON_HIP_TRY(hipMemsetAsync(rhist, 0, (size_t)R * 256 * sizeof(uint32_t), s));
     {
-        uint32_t per_block = (div_up(n, kNumCU) + 15u) & ~15u;
-        if (per_block < 4096) per_block = 4096;
-        const uint32_t ranges = div_up(n, per_block);
-        hipLaunchKernelGGL(bs::k_hist16, dim3(ranges, 2), dim3(bs::kH16Block), 0, s, d_x, n, B.hist16, per_block);
+        hipLaunchKernelGGL(bs::k_hist16, dim3(R, 2), dim3(bs::kH16Block), 0, s, d_x, n, B.hist16, tpr * (uint32_t)bs::kTile, rhist);
         hipLaunchKernelGGL(bs::k_prep16, dim3(1), dim3(1024), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 2;
@@ -267,23 +276,12 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         uint32_t *A_K = reinterpret_cast<uint32_t *>(B.keyA), *A_I = A_K + n + 8;
         uint32_t *B_K = reinterpret_cast<uint32_t *>(B.keyB), *B_I = B_K + n + 8;
         uint8_t *A_B1 = reinterpret_cast<uint8_t *>(B.valA);
-        const uint32_t ntiles = div_up(n, bs::kTile);
         bs::TieCtl h_ctl;
         memset(&h_ctl, 0, sizeof h_ctl);
         h_ctl.min_depth = 5;
         h_ctl.base_id = 0xFFFFFFFFu;
         h_ctl.list_cap = kTieListCap;
         ARCHON_HIP_TRY(hipMemcpyAsync(d_ctl, &h_ctl, sizeof h_ctl, hipMemcpyHostToDevice, s));
-        // R contiguous tile ranges, one persistent workgroup each (3 per CU)
-        const int geo = getenv("ARCHON_PASS_GEOMETRY") ? atoi(getenv("ARCHON_PASS_GEOMETRY")) : 0;   // 0: 512x16, 1: 1024x8
-        uint32_t R = (uint32_t)kNumCU * (geo == 1 ? 1 : 2);   // = co-resident workgroups
-        if (const char *e = getenv("ARCHON_PASS_RANGES")) R = (uint32_t)atoi(e);
-        if (R > (uint32_t)bs::kMaxRanges) R = bs::kMaxRanges;
-        if (R > ntiles) R = ntiles;
-        const uint32_t tpr = div_up(ntiles, R);
-        R = div_up(ntiles, tpr);
-        uint32_t *rhist = B.sc.d_status;            // [R][256], reused by both passes
-        hipLaunchKernelGGL(bs::k_range_hist_text, dim3(R), dim3(256), 0, s, d_x, n, tpr, rhist, 1u);
         pt.mark();
         if (geo == 1)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 8>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);

@@ -21,6 +21,9 @@ def oracle():
 @pytest.fixture(scope="session")
 def archon():
     """The HIP path through the C ABI.  Fails loudly when the extension is missing."""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()            # torch first: one HIP runtime initialisation order for the whole session
     import pyarchon
     pyarchon.lib()
     if pyarchon.device_count() < 1:
