@@ -1,0 +1,91 @@
+"""GPU: the a7 command-line surface (bin/archon e|d <in> <out>) and the C block-coder API
+(include/archon.h, libarchon.so) produce the reference's file layout, bit-exact with the oracle."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import archon_synth as S
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "bin", "archon")
+
+
+def _build():
+    if not os.path.exists(EXE) or not os.path.exists(os.path.join(ROOT, "dark-archon_amd", "libarchon.so")):
+        subprocess.run(["make", "-C", ROOT, "host", "cli"], check=True, capture_output=True)
+
+
+@pytest.mark.parametrize("shape,n", [("text", 65536), ("random", 1 << 20), ("ab", 40001), ("dna", 300000)])
+def test_cli_round_trip(archon, oracle, tmp_path, shape, n):
+    """configs[0]-style: encode with the CLI, compare the file with the oracle's BWT||baseId, decode, compare"""
+    _build()
+    x = S.gen_shape(shape, n)
+    raw, enc, dec = tmp_path / "in.raw", tmp_path / "out.bwt", tmp_path / "back.raw"
+    x.tofile(raw)
+    r = subprocess.run([EXE, "e", str(raw), str(enc)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "Validating...OK" in r.stdout and "SA time:" in r.stdout and "Done." in r.stdout
+    f = np.fromfile(enc, np.uint8)
+    assert f.size == n + 4                                   # N BWT bytes + uint32 LE index (archon.cpp:895,898)
+    _, B, base = oracle.forward(x)
+    assert (f[:-4] == B).all() and int(f[-4:].view("<u4")[0]) == base
+    r = subprocess.run([EXE, "d", str(enc), str(dec)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert (np.fromfile(dec, np.uint8) == x).all()
+
+
+def test_cli_decodes_reference_layout(archon, oracle, tmp_path):
+    """a file laid out by the oracle (= the reference's layout) decodes with the CLI"""
+    _build()
+    x = S.gen_text(50000)
+    _, B, base = oracle.forward(x)
+    enc = tmp_path / "ref.bwt"
+    with open(enc, "wb") as f:
+        f.write(B.tobytes() + int(base).to_bytes(4, "little"))
+    dec = tmp_path / "out.raw"
+    r = subprocess.run([EXE, "d", str(enc), str(dec)], capture_output=True, text=True)
+    assert r.returncode == 0 and (np.fromfile(dec, np.uint8) == x).all()
+
+
+def test_block_coder_c_api(archon, oracle, tmp_path):
+    """include/archon.h: create -> en_read -> en_compute -> validate -> en_write, P = SA in place"""
+    _build()
+    L = ctypes.CDLL(os.path.join(ROOT, "dark-archon_amd", "libarchon.so"))
+    libc = ctypes.CDLL(None)
+    libc.fopen.restype = ctypes.c_void_p
+    libc.fopen.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    libc.fclose.argtypes = [ctypes.c_void_p]
+    L.archon_create.restype = ctypes.c_void_p
+    L.archon_create.argtypes = [ctypes.c_uint32]
+    L.archon_sa.restype = ctypes.POINTER(ctypes.c_uint32)
+    for fn in ("archon_destroy", "archon_validate", "archon_en_compute", "archon_sa", "archon_base_id",
+               "archon_length", "archon_count_memory"):
+        getattr(L, fn).argtypes = [ctypes.c_void_p]
+    for fn in ("archon_en_read",):
+        getattr(L, fn).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    L.archon_en_write.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    n = 123457
+    x = S.gen_dna(n)
+    raw = tmp_path / "x.raw"
+    x.tofile(raw)
+    a = L.archon_create(n)
+    assert L.archon_count_memory(a) == n + (n + L.archon_estimate_reserve(n)) * 4      # 5N + O(1)
+    fx = libc.fopen(str(raw).encode(), b"rb")
+    assert L.archon_en_read(a, fx, n) == n
+    libc.fclose(fx)
+    assert L.archon_en_compute(a) == 0
+    assert L.archon_validate(a) == 1
+    P = np.ctypeslib.as_array(L.archon_sa(a), shape=(n,)).copy()
+    Pref, B, base = oracle.forward(x)
+    assert (P == Pref).all() and L.archon_base_id(a) == base
+    out = tmp_path / "x.bwt"
+    fo = libc.fopen(str(out).encode(), b"wb")
+    assert L.archon_en_write(a, fo) == 0
+    libc.fclose(fo)
+    L.archon_destroy(a)
+    f = np.fromfile(out, np.uint8)
+    assert (f[:-4] == B).all() and int(f[-4:].view("<u4")[0]) == base

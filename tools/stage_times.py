@@ -11,3 +11,11 @@ for r in range(reps):
     pyarchon.forward_dev(x, sa, bwt, base)
     st = pyarchon.stats()
     if r: print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items() if v}))
+
+if len(sys.argv) > 4 and sys.argv[4] == "inv":
+    out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    for r in range(3):
+        pyarchon.inverse_dev(bwt, int(base.item()), out)
+        st = pyarchon.stats()
+        print("inverse", json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items() if v}))
+    assert torch.equal(out, x)
