@@ -242,9 +242,12 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // A2 / bucket setup: the two-byte count (a4 compute(), archon.c:146-161) and its scans.  The count
     // runs over the tile ranges of LSB pass A (R contiguous ranges, one persistent workgroup each), so
     // the same sweep also delivers that pass's per-range digit table.
-    const int geo = getenv("ARCHON_PASS_GEOMETRY") ? atoi(getenv("ARCHON_PASS_GEOMETRY")) : 0;   // 0: 512x16, 1: 1024x8
-    const uint32_t ntiles = div_up(n, bs::kTile);
-    uint32_t R = (uint32_t)kNumCU * (geo == 1 ? 1 : 2);   // = co-resident workgroups
+    // pass geometries: 0: 512x16 = tiles of 8192, 2 workgroups/CU; 1: 1024x8, 1/CU; 2: 1024x16 = tiles of 16384, 1/CU
+    const int geo = getenv("ARCHON_PASS_GEOMETRY") ? atoi(getenv("ARCHON_PASS_GEOMETRY")) : 2;
+    const uint32_t tileA = geo == 2 ? 16384u : 8192u, tileB = tileA;
+    const uint32_t wg_per_cu = geo == 0 ? 2u : 1u;
+    const uint32_t ntiles = div_up(n, tileA);
+    uint32_t R = (uint32_t)kNumCU * wg_per_cu;            // = co-resident workgroups
     if (const char *e = getenv("ARCHON_PASS_RANGES")) R = (uint32_t)atoi(e);
     if (R > (uint32_t)bs::kMaxRanges) R = bs::kMaxRanges;
     if (R > ntiles) R = ntiles;
@@ -254,7 +257,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, 65536 * sizeof(uint32_t), s));
     ARCHON_HIP_TRY(hipMemsetAsync(rhist, 0, (size_t)R * 256 * sizeof(uint32_t), s));
     {
-        hipLaunchKernelGGL(bs::k_hist16, dim3(R, 2), dim3(bs::kH16Block), 0, s, d_x, n, B.hist16, tpr * (uint32_t)bs::kTile, rhist);
+        hipLaunchKernelGGL(bs::k_hist16, dim3(R, 2), dim3(bs::kH16Block), 0, s, d_x, n, B.hist16, tpr * tileA, rhist);
         hipLaunchKernelGGL(bs::k_prep16, dim3(1), dim3(1024), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 2;
@@ -284,26 +287,37 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ARCHON_HIP_TRY(hipMemcpyAsync(d_ctl, &h_ctl, sizeof h_ctl, hipMemcpyHostToDevice, s));
         pt.mark();
         if (geo == 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 8>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 8, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);
+        else if (geo == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 16>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 16, 4>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);
         pt.mark();
         ARCHON_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(bs::k_range_hist_text, dim3(R), dim3(256), 0, s, A_B1, n, tpr, rhist, 0u);
+        // pass B has its own tiling of the pass-A output
+        const uint32_t ntilesB = div_up(n, tileB);
+        uint32_t RB = (uint32_t)kNumCU * wg_per_cu;
+        if (RB > ntilesB) RB = ntilesB;
+        const uint32_t tprB = div_up(ntilesB, RB);
+        RB = div_up(ntilesB, tprB);
+        hipLaunchKernelGGL(bs::k_range_hist_text, dim3(RB), dim3(256), 0, s, A_B1, n, tprB, rhist, 0u, tileB);
         pt.mark();
         unsigned long long *d_stamps = reinterpret_cast<unsigned long long *>(small + 800);
         if (dbg & 4u)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, true>), dim3(R), dim3(512), 0, s, A_K, A_I, A_B1, n, tpr, B_K, B_I,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, 4, true>), dim3(RB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
                                B.prep->startB, rhist, dbg & 1u, d_stamps);
         else if (geo == 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 8, false>), dim3(R), dim3(1024), 0, s, A_K, A_I, A_B1, n, tpr, B_K, B_I,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 8, 4, false>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
+                               B.prep->startB, rhist, dbg, d_stamps);
+        else if (geo == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 16, 4, false>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
                                B.prep->startB, rhist, dbg, d_stamps);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, false>), dim3(R), dim3(512), 0, s, A_K, A_I, A_B1, n, tpr, B_K, B_I,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, 4, false>), dim3(RB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
                                B.prep->startB, rhist, dbg, d_stamps);
         pt.mark();
         ARCHON_HIP_TRY(hipGetLastError());
-        c->launches += 2;
+        c->launches += 3;
         e2 = tm.mark();
         if (dbg & 8u)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_local_sort<true>), dim3(65536), dim3(bs::kLsBlock), 0, s, B_K, B_I, B.prep->start16, n, sa,
