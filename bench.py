@@ -9,7 +9,9 @@ doubling -> sa_to_bwt, SA emitted) on its own 256 MiB block of uniform random
 bytes already resident in HBM (BASELINE.json configs[1], SURVEY.md 8(d) cfg 2;
 block b is seeded SEED_BASE+2+b), and for N>1 the per-block outputs BWT||baseId
 are gathered to rank 0 over RCCL (the path's one exchange step).
-Blocks are independent, per-GPU work is fixed: "scaling": "weak".
+The gather of step k is asynchronous (RCCL's own stream) and overlaps the sort of step k+1; the
+timed region ends only after every gather has completed.  Blocks are independent, per-GPU work is
+fixed: "scaling": "weak".
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline      the dominant kernel (LSB radix pass B, bs::k_pass_rec): algorithmic bytes per
@@ -125,16 +127,25 @@ def main():
     x = archon_synth.gen_shape(args.shape, n, block=rank)
     x_t = torch.from_numpy(x).to(dev)
     sa_t = None if args.no_sa else torch.empty(n, dtype=torch.int32, device=dev)
-    out_t = torch.empty(n + 4, dtype=torch.uint8, device=dev)       # BWT || baseId (LE)
+    # BWT || baseId (LE), double-buffered: the gather of step k runs on RCCL's stream while step k+1 sorts
+    outs = [torch.empty(n + 4, dtype=torch.uint8, device=dev) for _ in range(2)]
     base_t = torch.zeros(1, dtype=torch.int32, device=dev)
-    gather_list = None
+    gather_lists = [None, None]
     if dist is not None and rank == 0:
-        gather_list = [torch.empty(n + 4, dtype=torch.uint8, device=dev) for _ in range(world)]
+        gather_lists = [[torch.empty(n + 4, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(2)]
+    pending = [None, None]
     pyarchon.reserve(n, local_rank)
 
     pass_ms, pass_cnt, stage = [], [], []
+    step_no = [0]
 
     def step():
+        k = step_no[0] & 1
+        step_no[0] += 1
+        if pending[k] is not None:          # the buffer pair is free once its gather has completed
+            pending[k].wait()
+            pending[k] = None
+        out_t = outs[k]
         pyarchon.forward_dev(x_t, sa_t, out_t[:n], base_t)
         out_t[n:] = base_t.view(torch.uint8)
         st = pyarchon.stats(local_rank)
@@ -142,9 +153,13 @@ def main():
         pass_cnt.append(st["radix_pass_timed"])
         stage.append(st)
         if dist is not None:
-            dist.gather(out_t, gather_list, dst=0)
+            pending[k] = dist.gather(out_t, gather_lists[k], dst=0, async_op=True)
 
     def fence():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -206,7 +221,7 @@ def main():
                             % args.block_mib if args.shape == "random" else "%d MiB '%s' block per GPU" % (args.block_mib, args.shape),
                 "block_bytes": n,
                 "blocks_per_step": world,
-                "parallelism": "block-sharded x%d, one RCCL gather of BWT||baseId per step" % world if world > 1 else "single GPU",
+                "parallelism": "block-sharded x%d, one RCCL gather of BWT||baseId per step (async, overlapped with the next step)" % world if world > 1 else "single GPU",
                 "sa_emitted": sa_t is not None,
                 "sa_lf_consistent": ok,
             },
