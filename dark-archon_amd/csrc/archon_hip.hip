@@ -305,16 +305,16 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         unsigned long long *d_stamps = reinterpret_cast<unsigned long long *>(small + 800);
         if (dbg & 4u)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, 4, true>), dim3(RB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg & 1u, d_stamps);
+                               B.prep->startB, rhist, dbg & 1u, d_stamps, B.prep->startA);
         else if (geo == 1)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 8, 4, false>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg, d_stamps);
+                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA);
         else if (geo == 2)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 16, 4, false>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg, d_stamps);
+                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, 4, false>), dim3(RB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg, d_stamps);
+                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA);
         pt.mark();
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 3;
