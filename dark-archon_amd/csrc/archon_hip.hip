@@ -242,9 +242,9 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // A2 / bucket setup: the two-byte count (a4 compute(), archon.c:146-161) and its scans.  The count
     // runs over the tile ranges of LSB pass A (R contiguous ranges, one persistent workgroup each), so
     // the same sweep also delivers that pass's per-range digit table.
-    // pass geometries: 0: 512x16 = tiles of 8192, 2 workgroups/CU; 1: 1024x8, 1/CU; 2: 1024x16 = tiles of 16384, 1/CU
+    // pass geometries: 0: 512x16 = tiles of 8192, 2 workgroups/CU; 1: 1024x8, 1/CU; 2: 1024x16 = tiles of 16384, 1/CU; 3: 512x32 = tiles of 16384, 1/CU, 256 VGPRs
     const int geo = getenv("ARCHON_PASS_GEOMETRY") ? atoi(getenv("ARCHON_PASS_GEOMETRY")) : 2;
-    const uint32_t tileA = geo == 2 ? 16384u : 8192u, tileB = tileA;
+    const uint32_t tileA = geo >= 2 ? 16384u : 8192u, tileB = tileA;
     const uint32_t wg_per_cu = geo == 0 ? 2u : 1u;
     const uint32_t ntiles = div_up(n, tileA);
     uint32_t R = (uint32_t)kNumCU * wg_per_cu;            // = co-resident workgroups
@@ -290,6 +290,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 8, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);
         else if (geo == 2)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);
+        else if (geo == 3)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 32, 2>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 16, 4>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);
         pt.mark();
@@ -300,17 +302,20 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         if (RB > ntilesB) RB = ntilesB;
         const uint32_t tprB = div_up(ntilesB, RB);
         RB = div_up(ntilesB, tprB);
-        hipLaunchKernelGGL(bs::k_range_hist_text, dim3(RB), dim3(256), 0, s, A_B1, n, tprB, rhist, 0u, tileB);
+        hipLaunchKernelGGL(bs::k_range_hist_text, dim3(RB), dim3(bs::kRhBlock), 0, s, A_B1, n, tprB, rhist, 0u, tileB);
         pt.mark();
         unsigned long long *d_stamps = reinterpret_cast<unsigned long long *>(small + 800);
         if (dbg & 4u)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, 4, true>), dim3(RB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 16, 4, true>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
                                B.prep->startB, rhist, dbg & 1u, d_stamps, B.prep->startA);
         else if (geo == 1)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 8, 4, false>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
                                B.prep->startB, rhist, dbg, d_stamps, B.prep->startA);
         else if (geo == 2)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 16, 4, false>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
+                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA);
+        else if (geo == 3)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 32, 2, false>), dim3(RB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
                                B.prep->startB, rhist, dbg, d_stamps, B.prep->startA);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, 4, false>), dim3(RB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
