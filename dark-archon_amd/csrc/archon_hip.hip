@@ -127,7 +127,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
 {
     const uint32_t g256 = div_up(n, 256);
     ARCHON_TRY(launch_scan<1>(s, B.v, B.v, n, B.scan_tmp, nullptr));
-    hipLaunchKernelGGL(fwd::k_scatter_rank, dim3(g256), dim3(256), 0, s, sa, B.v, n, sa, B.rank, B.keep);
+    hipLaunchKernelGGL(fwd::k_keep_flags, dim3(g256), dim3(256), 0, s, B.v, n, B.keep);
     uint32_t *d_total = B.small + 600;
     ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, n, B.scan_tmp, d_total));
     ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -137,6 +137,9 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     st.unresolved_initial = m;
     int cur = 0;
     if (m) {
+        // ranks are needed only now (4N random stores): every item, not just the tied ones
+        hipLaunchKernelGGL(fwd::k_scatter_rank, dim3(g256), dim3(256), 0, s, sa, B.v, n, sa, B.rank, B.keep);
+        ++c->launches;
         hipLaunchKernelGGL(fwd::k_compact_first, dim3(g256), dim3(256), 0, s, B.keep, B.dst, B.v, sa, n, B.upos[0], B.ug[0],
                            B.uitem[0]);
         ++c->launches;
@@ -371,9 +374,32 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         e4 = e3;
     } else {
         // ---- first stage for heavily skewed blocks: 7 LSB passes on packed 7-byte keys ----
-        hipLaunchKernelGGL(fwd::k_init_keys, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, B.keyA, B.valA);
+        // alphabet compaction: with <= 16 distinct bytes the key holds 56/bits symbols
+        ARCHON_TRY(launch_hist256(s, d_x, n, d_counts, n));
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_counts, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        uint32_t sigma = 0;
+        uint8_t h_lut[256];
+        for (int v = 0; v < 256; ++v) {
+            h_lut[v] = (uint8_t)sigma;
+            if (c->h_mail[v]) ++sigma;
+        }
+        uint32_t bits = 1;
+        while ((1u << bits) < sigma) ++bits;
+        const bool packed = sigma <= 16 && !getenv("ARCHON_NO_PACK");
+        if (packed) {
+            h0 = 56 / bits;
+            uint8_t *d_lut = reinterpret_cast<uint8_t *>(small + 900);
+            memcpy(c->h_mail + 1024, h_lut, 256);
+            ARCHON_HIP_TRY(hipMemcpyAsync(d_lut, c->h_mail + 1024, 256, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(fwd::k_init_keys_packed, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, d_lut, bits, h0,
+                               B.keyA, B.valA);
+            st.alphabet_bits = bits;
+        } else {
+            hipLaunchKernelGGL(fwd::k_init_keys, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, B.keyA, B.valA);
+        }
         ARCHON_HIP_TRY(hipGetLastError());
-        ++c->launches;
+        c->launches += 2;
         bool in_b = false;
         ARCHON_TRY(rs::sort_pairs(s, B.sc, B.keyA, B.valA, B.keyB, B.valB, n, 0xFEu, &in_b, &st.radix_passes, &c->launches, &pt));
         uint64_t *kS = in_b ? B.keyB : B.keyA;

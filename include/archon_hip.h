@@ -135,6 +135,8 @@ typedef struct archon_hip_stats {
     uint32_t tie_items;          /* rows flagged as tied by k_local_sort */
     float ms_pass_text;          /* streaming path: LSB pass A (k_pass_text), its own HIP events */
     float ms_pass_rec;           /* streaming path: LSB pass B (k_pass_rec), its own HIP events */
+    uint32_t alphabet_bits;      /* 7-pass path: bits per symbol when the alphabet was compacted (0 = bytes) */
+    uint32_t reserved2;
 } archon_hip_stats;
 
 int archon_hip_get_stats(int dev, archon_hip_stats *out);

@@ -167,3 +167,30 @@ def test_large_shapes_lf_consistent(archon, shape):
     out_t = torch.empty(n, dtype=torch.uint8, device="cuda")
     archon.inverse_dev(bwt_t, int(base_t.item()), out_t)
     assert torch.equal(out_t, x_t)
+
+
+def test_alphabet_compaction(archon, oracle):
+    """SURVEY 8(f) N2: with <= 16 distinct bytes the 7-pass route packs 56/bits symbols per key;
+    packed and byte keys must give the same SA (and the oracle's), also at the 16/17-symbol edge."""
+    import os
+    rng = np.random.default_rng(11)
+    cases = [S.gen_dna(200000), S.gen_repeat(70001, b"ab"), S.gen_repeat(5000, b"a"),
+             rng.choice(np.arange(100, 116, dtype=np.uint8), size=150000),          # 16 symbols -> 4 bits
+             rng.choice(np.arange(100, 117, dtype=np.uint8), size=150000),          # 17 symbols -> bytes
+             rng.choice(np.array([0, 255], np.uint8), size=100000),                 # codes 0/1 with 0xFF present
+             rng.choice(np.array([7, 9, 200], np.uint8), size=90000, p=[0.9, 0.05, 0.05])]
+    for x in cases:
+        os.environ["ARCHON_FORCE_PATH"] = "0"
+        try:
+            sa1, bwt1, b1 = archon.forward(x)
+            bits = archon.stats()["alphabet_bits"]
+            os.environ["ARCHON_NO_PACK"] = "1"
+            sa2, bwt2, b2 = archon.forward(x)
+            assert archon.stats()["alphabet_bits"] == 0
+        finally:
+            os.environ.pop("ARCHON_NO_PACK", None)
+            os.environ.pop("ARCHON_FORCE_PATH", None)
+        nsym = len(np.unique(x))
+        assert (bits > 0) == (nsym <= 16), (nsym, bits)
+        P, B, b0 = oracle.forward(x)
+        assert (sa1 == P).all() and (sa2 == P).all() and (bwt1 == B).all() and b1 == b0 == b2
