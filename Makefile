@@ -26,9 +26,9 @@ $(PKG)/libarchon.so: $(PKG)/host/archon_host.cpp $(PKG)/host/archon_host.h inclu
 
 cli: bin/archon
 
-bin/archon: $(PKG)/host/archon_host.cpp $(PKG)/host/archon_main.cpp $(PKG)/host/archon_host.h include/archon.h $(LIB)
+bin/archon: $(PKG)/host/archon_host.cpp $(PKG)/host/archon_main.cpp $(PKG)/host/archon_container.cpp $(PKG)/host/archon_host.h include/archon.h $(LIB)
 	@mkdir -p bin
-	$(CXX) -O2 -std=c++17 -Wall -Iinclude -o $@ $(PKG)/host/archon_main.cpp $(PKG)/host/archon_host.cpp \
+	$(CXX) -O2 -std=c++17 -Wall -pthread -Iinclude -o $@ $(PKG)/host/archon_main.cpp $(PKG)/host/archon_host.cpp $(PKG)/host/archon_container.cpp \
 	    -L$(PKG) -larchon_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)'
 
 oracle:

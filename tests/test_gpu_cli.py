@@ -89,3 +89,43 @@ def test_block_coder_c_api(archon, oracle, tmp_path):
     L.archon_destroy(a)
     f = np.fromfile(out, np.uint8)
     assert (f[:-4] == B).all() and int(f[-4:].view("<u4")[0]) == base
+
+
+@pytest.mark.parametrize("n,bs", [(300000, "64k"), (262144, "64k"), (1000, "4096"), (5 << 20, "1m")])
+def test_container_round_trip(archon, oracle, tmp_path, n, bs):
+    """ArchonX3's multi-block container with a7-order blocks: header 'RA' + block size,
+    per block BWT||index, a short (possibly empty) block ends the file; every block equals the oracle's."""
+    _build()
+    x = S.gen_text(n)
+    raw, enc, dec = tmp_path / "in.raw", tmp_path / "out.x3", tmp_path / "back.raw"
+    x.tofile(raw)
+    r = subprocess.run([EXE, "e", "-b" + bs, str(raw), str(enc)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    f = np.fromfile(enc, np.uint8)
+    bsize = int(bs[:-1]) << (20 if bs[-1] == "m" else 10) if bs[-1] in "km" else int(bs)
+    assert f[:2].tobytes() == b"AR" and int(f[2:6].view("<u4")[0]) == bsize
+    off, pos, nblocks = 6, 0, 0
+    while True:
+        ln = min(bsize, n - pos)
+        blk = f[off:off + ln]
+        idx = int(f[off + ln:off + ln + 4].view("<u4")[0])
+        if ln:
+            _, B, base = oracle.forward(x[pos:pos + ln])
+            assert (blk == B).all() and idx == base
+        off += ln + 4
+        pos += ln
+        nblocks += 1
+        if ln < bsize:
+            break
+    assert off == f.size and nblocks == n // bsize + 1
+    r = subprocess.run([EXE, "d", "-b", str(enc), str(dec)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert (np.fromfile(dec, np.uint8) == x).all()
+
+
+def test_container_rejects_plain_file(archon, tmp_path):
+    _build()
+    p = tmp_path / "plain"
+    p.write_bytes(b"not a container at all")
+    r = subprocess.run([EXE, "d", "-b", str(p), str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode != 0
