@@ -97,7 +97,7 @@ static size_t forward_arena_bytes(uint32_t n)
     add(4 * (N + 1));               // rank
     add(4 * N);                     // sa (when the caller wants none)
     add(4 * N); add(4 * N); add(4 * N);       // v / gstart, keep, dst
-    for (int i = 0; i < 6; ++i) add(4 * N);   // upos, ug, uitem (double-buffered)
+    for (int i = 0; i < 7; ++i) add(4 * N);   // upos, ug, uitem (double-buffered) + the initial rows
     add(4 * scan_temp_words(N));
     add(4 * rs::status_words(n));
     add(4 * 8 * 256); add(4 * 8 * 256);       // ghist, gstart
@@ -112,7 +112,7 @@ struct FwdBuf {
     uint8_t *xa;
     uint64_t *keyA, *keyB;
     uint32_t *valA, *valB, *rank, *sa_own, *v, *keep, *dst;
-    uint32_t *upos[2], *ug[2], *uitem[2];
+    uint32_t *upos[2], *ug[2], *uitem[2], *uinit;
     uint32_t *scan_tmp, *hist16, *small;
     bs::Prep *prep;
     uint2 *tie_list;
@@ -142,8 +142,10 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         ++c->launches;
         hipLaunchKernelGGL(fwd::k_compact_first, dim3(g256), dim3(256), 0, s, B.keep, B.dst, B.v, sa, n, B.upos[0], B.ug[0],
                            B.uitem[0]);
-        ++c->launches;
+        ARCHON_HIP_TRY(hipMemcpyAsync(B.uinit, B.upos[0], (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        c->launches += 2;
     }
+    const uint32_t m0 = m;
     uint64_t *kT = B.keyA, *kS = B.keyB;
     uint32_t *vT = B.valA, *vS = B.valB;
     uint32_t h = h0;
@@ -180,6 +182,12 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         }
         h = h > 0x40000000u ? 0x80000000u : h * 2;
     }
+    // A7 for the rows the doubling rounds moved (every other row already holds its symbol)
+    if (m0) {
+        hipLaunchKernelGGL(fwd::k_bwt_fix, dim3(div_up(m0, 256)), dim3(256), 0, s, d_x, sa, B.uinit, m0, n, d_bwt, d_base);
+        ARCHON_HIP_TRY(hipGetLastError());
+        ++c->launches;
+    }
     return ARCHON_OK;
 }
 
@@ -209,6 +217,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         B.ug[i] = c->alloc<uint32_t>(n);
         B.uitem[i] = c->alloc<uint32_t>(n);
     }
+    B.uinit = c->alloc<uint32_t>(n);
     B.scan_tmp = c->alloc<uint32_t>(scan_temp_words(n));
     B.sc.d_status = c->alloc<uint32_t>(rs::status_words(n));
     B.sc.d_ghist = c->alloc<uint32_t>(8 * 256);
@@ -369,6 +378,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         } else {
             h0 = h_ctl.min_depth < 5 ? h_ctl.min_depth : 5;
             hipLaunchKernelGGL(bs::k_flags_from_sa, dim3(g256), dim3(256), 0, s, sa, n, B.v);
+            ARCHON_HIP_TRY(hipMemcpyAsync(d_base, &d_ctl->base_id, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
             ++c->launches;
         }
         e4 = e3;
@@ -406,7 +416,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         uint32_t *vS = in_b ? B.valB : B.valA;
         e2 = tm.mark();
         hipLaunchKernelGGL(fwd::k_flag_boundaries, dim3(g256), dim3(256), 0, s, kS, n, B.v);
-        ARCHON_HIP_TRY(hipMemcpyAsync(sa, vS, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(fwd::k_bwt_from_keys, dim3(g256), dim3(256), 0, s, kS, vS, n, sa, d_bwt, d_base);
         c->launches += 2;
         e3 = e2;
     }
@@ -414,10 +424,6 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     if (need_general) {
         ARCHON_TRY(general_stage(c, s, B, d_x, n, sa, h0, d_bwt, d_base, st));
         e4 = tm.mark();
-        // A7: SA -> BWT + primary index
-        hipLaunchKernelGGL(fwd::k_sa_to_bwt, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, sa, n, d_bwt, d_base);
-        ARCHON_HIP_TRY(hipGetLastError());
-        ++c->launches;
         ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, d_base, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
     const int e5 = tm.mark();
