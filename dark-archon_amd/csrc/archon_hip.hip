@@ -135,6 +135,42 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     c->launches += 7;
     uint32_t m = c->h_mail[0];
     st.unresolved_initial = m;
+    // long-repeat defence: when much of the block is tied and one neighbour gap dominates the tied groups,
+    // settle the periodic runs directly (forward.hiph, k_chain_*) before any doubling round
+    if (m >= n / 16 && !getenv("ARCHON_NO_CHAINS")) {
+        uint32_t *tab = B.upos[0];                      // 2 * kGapSlots words; upos is idle until the compaction
+        ARCHON_HIP_TRY(hipMemsetAsync(tab, 0, 2 * fwd::kGapSlots * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(fwd::k_gap_sample, dim3(div_up(div_up(n, fwd::kGapStride), 256)), dim3(256), 0, s, sa, B.v, n, tab);
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, tab, 2 * fwd::kGapSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        c->launches += 1;
+        uint64_t total = 0;
+        uint32_t best = 0;
+        for (uint32_t i = 0; i < fwd::kGapSlots; ++i) {
+            total += c->h_mail[i];
+            if (c->h_mail[i] > c->h_mail[best]) best = i;
+        }
+        const uint32_t p = c->h_mail[fwd::kGapSlots + best];
+        if (p >= 1 && p < n && (uint64_t)c->h_mail[best] * 4 >= total) {
+            uint32_t *brk = B.rank, *ginfo = B.dst, *gend = B.keep, *settled = B.small + 601;
+            hipLaunchKernelGGL(fwd::k_period_breaks, dim3(g256), dim3(256), 0, s, d_x, n, p, brk);
+            ARCHON_TRY(launch_scan<1>(s, brk, brk, n, B.scan_tmp, nullptr));
+            ARCHON_HIP_TRY(hipMemsetAsync(ginfo, 0, (size_t)n * sizeof(uint32_t), s));
+            ARCHON_HIP_TRY(hipMemsetAsync(settled, 0, sizeof(uint32_t), s));
+            hipLaunchKernelGGL(fwd::k_chain_probe, dim3(g256), dim3(256), 0, s, d_x, sa, B.v, brk, n, p, ginfo, gend);
+            hipLaunchKernelGGL(fwd::k_chain_apply, dim3(g256), dim3(256), 0, s, sa, B.v, ginfo, gend, n, d_bwt, d_base, settled);
+            // the tied set again, without the settled groups
+            hipLaunchKernelGGL(fwd::k_keep_flags, dim3(g256), dim3(256), 0, s, B.v, n, B.keep);
+            ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, n, B.scan_tmp, d_total));
+            ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 1, settled, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            ARCHON_HIP_TRY(hipStreamSynchronize(s));
+            c->launches += 10;
+            m = c->h_mail[0];
+            st.period = p;
+            st.chain_items = c->h_mail[1];
+        }
+    }
     int cur = 0;
     if (m) {
         // ranks are needed only now (4N random stores): every item, not just the tied ones

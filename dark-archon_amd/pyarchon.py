@@ -40,7 +40,8 @@ class Stats(ctypes.Structure):
         ("ms_radix_pass_sum", ctypes.c_float), ("ms_local_sort", ctypes.c_float), ("ms_resolve", ctypes.c_float),
         ("path", ctypes.c_uint32), ("tie_groups", ctypes.c_uint32), ("tie_items", ctypes.c_uint32),
         ("ms_pass_text", ctypes.c_float), ("ms_pass_rec", ctypes.c_float),
-        ("alphabet_bits", ctypes.c_uint32), ("_pad3", ctypes.c_uint32),
+        ("alphabet_bits", ctypes.c_uint32), ("period", ctypes.c_uint32),
+        ("chain_items", ctypes.c_uint32), ("_pad3", ctypes.c_uint32),
     ]
 
     def asdict(self):

@@ -136,6 +136,8 @@ typedef struct archon_hip_stats {
     float ms_pass_text;          /* streaming path: LSB pass A (k_pass_text), its own HIP events */
     float ms_pass_rec;           /* streaming path: LSB pass B (k_pass_rec), its own HIP events */
     uint32_t alphabet_bits;      /* 7-pass path: bits per symbol when the alphabet was compacted (0 = bytes) */
+    uint32_t period;             /* long-repeat defence: the neighbour gap p it ran with (0 = not run) */
+    uint32_t chain_items;        /* rows it settled without doubling */
     uint32_t reserved2;
 } archon_hip_stats;
 

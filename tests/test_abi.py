@@ -38,7 +38,7 @@ def test_host_library_exports_header():
 
 def test_stats_struct_size():
     import pyarchon
-    assert ctypes.sizeof(pyarchon.Stats) == 120   # sizeof(archon_hip_stats)
+    assert ctypes.sizeof(pyarchon.Stats) == 128   # sizeof(archon_hip_stats)
 
 
 def test_no_cpu_fallback():

@@ -194,3 +194,46 @@ def test_alphabet_compaction(archon, oracle):
         assert (bits > 0) == (nsym <= 16), (nsym, bits)
         P, B, b0 = oracle.forward(x)
         assert (sa1 == P).all() and (sa2 == P).all() and (bwt1 == B).all() and b1 == b0 == b2
+
+
+def _repeat_cases():
+    rng = np.random.default_rng(31)
+    motif = rng.integers(0, 256, size=1000, dtype=np.uint8)
+    short = np.frombuffer(b"abcabd", np.uint8)
+    a = lambda k, c=97: np.full(k, c, np.uint8)
+    r = lambda k: rng.integers(0, 256, size=k, dtype=np.uint8)
+    lit = lambda s: np.frombuffer(s, np.uint8)
+    return {
+        "a": a(300000),
+        "ab": np.tile(lit(b"ab"), 150000),
+        "ba_odd": np.tile(lit(b"ba"), 150000)[:-1],
+        "motif1000": np.tile(motif, 300),
+        "motif1000_ragged": np.tile(motif, 300)[137:-451],
+        "motif6": np.tile(short, 50000),
+        "ff": a(200000, 255),
+        "feff": np.tile(np.array([254, 255], np.uint8), 100000),
+        "three_runs": np.concatenate([a(100000), lit(b"b"), a(100000), lit(b"c"), a(70000), lit(b"\x00"), a(30000)]),
+        "run_inside_random": np.concatenate([r(5000), np.tile(motif, 250), r(5000)]),
+        "two_periods": np.concatenate([np.tile(lit(b"ab"), 80000), np.tile(lit(b"abc"), 60000)]),
+        "run_signs": np.concatenate([lit(b"z"), a(60000), lit(b"A"), a(60000), lit(b"z"), a(60001), lit(b"a"), a(5)]),
+        "motif_with_glitches": np.concatenate([np.tile(motif, 100), motif[:500], lit(b"!"), np.tile(motif, 100), motif[:3]]),
+        "nested": np.tile(np.concatenate([a(500), lit(b"b")]), 400),
+    }
+
+
+@pytest.mark.parametrize("name", sorted(_repeat_cases()))
+def test_long_repeats(archon, oracle, name):
+    """Gauntlet-style periodic inputs (BASELINE.json configs[2]): the run shortcut (k_chain_*) and the doubling
+    rounds behind it must give the a7 order whatever mix of runs, periods and run boundaries the block holds."""
+    x = _repeat_cases()[name]
+    sa, bwt, base = archon.forward(x)
+    P, B, b0 = oracle.forward(x)
+    assert (sa == P).all()
+    assert (bwt == B).all() and base == b0
+
+
+def test_long_repeats_use_the_shortcut(archon):
+    x = np.tile(np.frombuffer(b"ab", np.uint8), 1 << 20)
+    archon.forward(x)
+    st = archon.stats()
+    assert st["period"] == 2 and st["chain_items"] > x.size * 0.99 and st["doubling_rounds"] == 0
