@@ -92,6 +92,7 @@ static size_t forward_arena_bytes(uint32_t n)
     size_t b = 0;
     auto add = [&](size_t bytes) { b += (bytes + 255) & ~size_t(255); };
     add(N + 64);                    // aligned copy of x (when needed)
+    add(N + 64);                    // packed key text y (compacted alphabets)
     add(8 * N + 64); add(8 * N + 64);   // keyA keyB  (fast path: K,I of pass A / pass B)
     add(4 * N + 64); add(4 * N + 64);   // valA valB  (fast path: CB of pass A, C of pass B)
     add(4 * (N + 1));               // rank
@@ -113,6 +114,7 @@ struct FwdBuf {
     uint64_t *keyA, *keyB;
     uint32_t *valA, *valB, *rank, *sa_own, *v, *keep, *dst;
     uint32_t *upos[2], *ug[2], *uitem[2], *uinit;
+    uint8_t *y;
     uint32_t *scan_tmp, *hist16, *small;
     bs::Prep *prep;
     uint2 *tie_list;
@@ -239,6 +241,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
 
     FwdBuf B;
     B.xa = c->alloc<uint8_t>((size_t)n + 64);
+    B.y = c->alloc<uint8_t>((size_t)n + 64);
     B.keyA = c->alloc<uint64_t>((size_t)n + 8);
     B.keyB = c->alloc<uint64_t>((size_t)n + 8);
     B.valA = c->alloc<uint32_t>((size_t)n + 16);
@@ -291,7 +294,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // runs over the tile ranges of LSB pass A (R contiguous ranges, one persistent workgroup each), so
     // the same sweep also delivers that pass's per-range digit table.
     // pass geometries: 0: 512x16 = tiles of 8192, 2 workgroups/CU; 1: 1024x8, 1/CU; 2: 1024x16 = tiles of 16384, 1/CU; 3: 512x32 = tiles of 16384, 1/CU, 256 VGPRs
-    const int geo = getenv("ARCHON_PASS_GEOMETRY") ? atoi(getenv("ARCHON_PASS_GEOMETRY")) : 2;
+    const int geo = getenv("ARCHON_PASS_GEOMETRY") ? atoi(getenv("ARCHON_PASS_GEOMETRY")) : 2;   // compacted alphabets: 2 only
     const uint32_t tileA = geo >= 2 ? 16384u : 8192u, tileB = tileA;
     const uint32_t wg_per_cu = geo == 0 ? 2u : 1u;
     const uint32_t ntiles = div_up(n, tileA);
@@ -302,20 +305,67 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     const uint32_t tpr = div_up(ntiles, R);
     R = div_up(ntiles, tpr);
     uint32_t *rhist = B.sc.d_status;            // [R][256], reused by both passes
-    ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, 65536 * sizeof(uint32_t), s));
-    ARCHON_HIP_TRY(hipMemsetAsync(rhist, 0, (size_t)R * 256 * sizeof(uint32_t), s));
-    {
-        hipLaunchKernelGGL(bs::k_hist16, dim3(R, 2), dim3(bs::kH16Block), 0, s, d_x, n, B.hist16, tpr * tileA, rhist);
+    // Q = symbols per key byte of the streaming stage: 1 = plain bytes; 2/4/8 = compacted alphabet (below)
+    auto count16 = [&](int Q, const uint8_t *src, uint32_t *big_items) -> int {
+        ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, 65536 * sizeof(uint32_t), s));
+        ARCHON_HIP_TRY(hipMemsetAsync(rhist, 0, (size_t)R * 256 * sizeof(uint32_t), s));
+        const dim3 grid(R, 2), block(bs::kH16Block);
+        if (Q == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<1>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
+        else if (Q == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<2>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
+        else if (Q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<4>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
         hipLaunchKernelGGL(bs::k_prep16, dim3(1), dim3(1024), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 2;
-    }
-    ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, &B.prep->big_items, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    const int e1 = tm.mark();
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
-    const uint32_t big_items = c->h_mail[0];
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, &B.prep->big_items, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        *big_items = c->h_mail[0];
+        return ARCHON_OK;
+    };
+    uint32_t big_items = 0;
+    ARCHON_TRY(count16(1, d_x, &big_items));
     int path = (uint64_t)big_items * 2 <= n ? 1 : 0;
     if (const char *f = getenv("ARCHON_FORCE_PATH")) path = atoi(f) ? 1 : 0;
+    int Q = 1;                                   // symbols per key byte on the streaming path
+    const uint8_t *d_y = d_x;                    // its key text
+    uint32_t sigma = 0, bits = 8;
+    uint8_t *d_lut = reinterpret_cast<uint8_t *>(small + 900);
+    if (path == 0) {
+        // heavily skewed at two bytes.  Alphabet compaction: with <= 16 distinct bytes a key
+        // byte holds 2, 4 or 8 symbols; if the two-byte buckets of THAT text are small enough the block still
+        // takes the streaming stage (DNA: 8 symbols deep after two passes), else the 7-pass sort on packed keys.
+        ARCHON_TRY(launch_hist256(s, d_x, n, d_counts, n));
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_counts, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        uint8_t h_lut[256];
+        for (int v = 0; v < 256; ++v) {
+            h_lut[v] = (uint8_t)sigma;
+            if (c->h_mail[v]) ++sigma;
+        }
+        bits = 1;
+        while ((1u << bits) < sigma) ++bits;
+        if (sigma <= 16 && !getenv("ARCHON_NO_PACK")) {
+            memcpy(c->h_mail + 1024, h_lut, 256);
+            ARCHON_HIP_TRY(hipMemcpyAsync(d_lut, c->h_mail + 1024, 256, hipMemcpyHostToDevice, s));
+            ARCHON_HIP_TRY(hipStreamSynchronize(s));          // h_mail is reused below
+            if (sigma >= 2 && geo == 2 && !getenv("ARCHON_FORCE_PATH") && !getenv("ARCHON_NO_PACK_STREAM")) {
+                const int q = bits == 1 ? 8 : bits == 2 ? 4 : 2;
+                const dim3 grid(div_up(div_up(n, 4), 256)), block(256);
+                if (q == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_build_y<8>), grid, block, 0, s, d_x, n, d_lut, B.y);
+                else if (q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_build_y<4>), grid, block, 0, s, d_x, n, d_lut, B.y);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_build_y<2>), grid, block, 0, s, d_x, n, d_lut, B.y);
+                ++c->launches;
+                ARCHON_TRY(count16(q, B.y, &big_items));
+                if ((uint64_t)big_items * 2 <= n) {
+                    path = 1;
+                    Q = q;
+                    d_y = B.y;
+                    st.alphabet_bits = 8 / q;
+                }
+            }
+        }
+    }
+    const int e1 = tm.mark();
     st.path = (uint32_t)path;
 
     const uint32_t dbg = getenv("ARCHON_DEBUG") ? (uint32_t)atoi(getenv("ARCHON_DEBUG")) : 0u;   // timing experiments only
@@ -334,14 +384,20 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         h_ctl.list_cap = kTieListCap;
         ARCHON_HIP_TRY(hipMemcpyAsync(d_ctl, &h_ctl, sizeof h_ctl, hipMemcpyHostToDevice, s));
         pt.mark();
-        if (geo == 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 8, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);
+        if (Q == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 2>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_y);
+        else if (Q == 4)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_y);
+        else if (Q == 8)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 8>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_y);
+        else if (geo == 1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 8, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
         else if (geo == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
         else if (geo == 3)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 32, 2>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 32, 2>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 16, 4>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 16, 4>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
         pt.mark();
         ARCHON_HIP_TRY(hipGetLastError());
         // pass B has its own tiling of the pass-A output
@@ -381,7 +437,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ARCHON_HIP_TRY(hipGetLastError());
         const int e2b = tm.mark();
         hipLaunchKernelGGL(bs::k_resolve_ties, dim3(div_up(kTieListCap, 256)), dim3(256), 0, s, d_x, n, B.tie_list, d_ctl,
-                           sa, d_bwt, 5u, 64u);
+                           sa, d_bwt, 5u * (uint32_t)Q, 64u * (uint32_t)Q);
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 4;
         st.radix_passes = 2;
@@ -412,7 +468,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             if (h_ctl.base_id >= n) { set_error("primary index not found"); return ARCHON_E_INTERNAL; }
             ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, &d_ctl->base_id, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         } else {
-            h0 = h_ctl.min_depth < 5 ? h_ctl.min_depth : 5;
+            h0 = (h_ctl.min_depth < 5 ? h_ctl.min_depth : 5) * (uint32_t)Q;     // key bytes -> symbols
             hipLaunchKernelGGL(bs::k_flags_from_sa, dim3(g256), dim3(256), 0, s, sa, n, B.v);
             ARCHON_HIP_TRY(hipMemcpyAsync(d_base, &d_ctl->base_id, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
             ++c->launches;
@@ -421,23 +477,9 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     } else {
         // ---- first stage for heavily skewed blocks: 7 LSB passes on packed 7-byte keys ----
         // alphabet compaction: with <= 16 distinct bytes the key holds 56/bits symbols
-        ARCHON_TRY(launch_hist256(s, d_x, n, d_counts, n));
-        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_counts, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
-        uint32_t sigma = 0;
-        uint8_t h_lut[256];
-        for (int v = 0; v < 256; ++v) {
-            h_lut[v] = (uint8_t)sigma;
-            if (c->h_mail[v]) ++sigma;
-        }
-        uint32_t bits = 1;
-        while ((1u << bits) < sigma) ++bits;
         const bool packed = sigma <= 16 && !getenv("ARCHON_NO_PACK");
         if (packed) {
             h0 = 56 / bits;
-            uint8_t *d_lut = reinterpret_cast<uint8_t *>(small + 900);
-            memcpy(c->h_mail + 1024, h_lut, 256);
-            ARCHON_HIP_TRY(hipMemcpyAsync(d_lut, c->h_mail + 1024, 256, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(fwd::k_init_keys_packed, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, d_lut, bits, h0,
                                B.keyA, B.valA);
             st.alphabet_bits = bits;

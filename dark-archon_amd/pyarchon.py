@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libarchon_hip.so")
+LIB_PATH = os.environ.get("ARCHON_HIP_LIB") or os.path.join(_HERE, "libarchon_hip.so")   # override: A/B builds only
 
 OK, E_ARG, E_NODEVICE, E_NOMEM, E_HIP, E_INTERNAL, E_CORRUPT = 0, -1, -2, -3, -4, -5, -6
 MAX_N = 0x3FFFFF00

@@ -237,3 +237,40 @@ def test_long_repeats_use_the_shortcut(archon):
     archon.forward(x)
     st = archon.stats()
     assert st["period"] == 2 and st["chain_items"] > x.size * 0.99 and st["doubling_rounds"] == 0
+
+
+@pytest.mark.parametrize("sigma", [2, 3, 4, 5, 9, 16])
+@pytest.mark.parametrize("n", [70001, 1 << 20])
+def test_compacted_alphabet_streaming(archon, oracle, sigma, n):
+    """<= 16 distinct bytes -> key bytes of 8/4/2 symbols (k_build_y) through the streaming
+    stage.  Symbols are spread over the byte range so that the order-preserving recode matters; the block
+    starts with a run of the largest symbol (ties with the end-of-string padding)."""
+    rng = np.random.default_rng(100 + sigma)
+    alpha = np.sort(rng.choice(256, size=sigma, replace=False)).astype(np.uint8)
+    alpha[-1] = 255 if sigma % 2 else alpha[-1]
+    x = alpha[rng.integers(0, sigma, size=n)]
+    x[:37] = alpha[-1]
+    sa, bwt, base = archon.forward(x)
+    st = archon.stats()
+    P, B, b0 = oracle.forward(x)
+    assert (sa == P).all()
+    assert (bwt == B).all() and base == b0
+    # two-byte buckets small enough already (n / sigma^2 under the 4608-item cap): plain bytes, no recode
+    want_bits = 0 if n / sigma**2 < 4400 else (1 if sigma == 2 else 2 if sigma <= 4 else 4)
+    assert st["path"] == 1 and st["alphabet_bits"] == want_bits
+
+
+def test_compacted_alphabet_with_repeats(archon, oracle):
+    """small alphabet + repeated material: streaming stage on packed bytes, then oversize buckets / deep ties
+    go to the doubling stage with the depth counted in symbols"""
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    chunk = acgt[rng.integers(0, 4, size=50000)]
+    x = np.concatenate([acgt[rng.integers(0, 4, size=400000)], chunk, acgt[rng.integers(0, 4, size=1000)], chunk,
+                        np.full(3000, ord("A"), np.uint8), chunk[:20000], acgt[rng.integers(0, 4, size=300000)]])
+    sa, bwt, base = archon.forward(x)
+    st = archon.stats()
+    P, B, b0 = oracle.forward(x)
+    assert (sa == P).all()
+    assert (bwt == B).all() and base == b0
+    assert st["path"] == 1 and st["alphabet_bits"] == 2 and st["doubling_rounds"] > 0
