@@ -1,0 +1,22 @@
+#!/bin/bash
+# usage: tools/evidence.sh <tag>   (on the GPU box, from the repo root)
+# Collects what profiles/<tag>/ holds: the bench line, rocprofv3 kernel stats of the same command,
+# the two PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) and the per-shape stage times.
+set -o pipefail
+tag=$1
+out=gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+timeout -k 10 400 python3 bench.py --steps 5 --warmup 1 > $out/bench_line.json 2> $out/bench.err || exit 1
+echo "bench done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/stats.log 2>&1 || exit 1
+echo "stats done"
+bash tools/pmc.sh $tag/pmc fetch FETCH_SIZE -- 256 random 3 || exit 1
+bash tools/pmc.sh $tag/pmc write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- 256 random 3 || exit 1
+python3 tools/pmc_summary.py $out/pmc > $out/pmc_fetch_write.txt 2>&1
+echo "pmc done"
+for sh in random dna text a ab motif; do
+  timeout -k 10 120 python3 tools/stage_times.py 256 $sh 3 2>/dev/null | tail -1 | sed "s/^/$sh /" >> $out/stage_times.txt || exit 1
+done
+timeout -k 10 120 python3 tools/stage_times.py 256 random 3 inv 2>/dev/null | tail -1 | sed "s/^/inverse-random /" >> $out/stage_times.txt
+cat $out/stage_times.txt
