@@ -306,7 +306,37 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     R = div_up(ntiles, tpr);
     uint32_t *rhist = B.sc.d_status;            // [R][256], reused by both passes
     // Q = symbols per key byte of the streaming stage: 1 = plain bytes; 2/4/8 = compacted alphabet (below)
-    auto count16 = [&](int Q, const uint8_t *src, uint32_t *big_items) -> int {
+    StageTimer ps(s);                            // streaming stage: pass A, pass B (their own HIP events)
+    int iA0 = -1, iA1 = -1, iB0 = -1, iB1 = -1;
+    uint32_t *A_K = reinterpret_cast<uint32_t *>(B.keyA), *A_I = A_K + n + 8;
+    uint8_t *A_B1 = reinterpret_cast<uint8_t *>(B.valA);
+    const uint32_t dbg = getenv("ARCHON_DEBUG") ? (uint32_t)atoi(getenv("ARCHON_DEBUG")) : 0u;   // timing experiments only
+    auto launch_pass_a = [&](int Q, const uint8_t *key_text) -> int {
+        iA0 = ps.mark();
+        if (Q == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 2>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, key_text);
+        else if (Q == 4)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, key_text);
+        else if (Q == 8)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 8>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, key_text);
+        else if (geo == 1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 8, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
+        else if (geo == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
+        else if (geo == 3)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 32, 2>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 16, 4>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
+        iA1 = ps.mark();
+        ARCHON_HIP_TRY(hipGetLastError());
+        ++c->launches;
+        return ARCHON_OK;
+    };
+    // The two-byte count decides the route, and the host has to see it.  ARCHON_SPECULATE=1 queues pass A of the
+    // streaming stage BEFORE the host waits; measured: the round trip costs < 0.03 ms per block while a block that
+    // turns out skewed pays a wasted pass (1.3-1.8 ms per 256 MiB on DNA / text), so it is off by default.
+    int e1 = -1;
+    auto count16 = [&](int Q, const uint8_t *src, uint32_t *big_items, bool speculate) -> int {
         ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, 65536 * sizeof(uint32_t), s));
         ARCHON_HIP_TRY(hipMemsetAsync(rhist, 0, (size_t)R * 256 * sizeof(uint32_t), s));
         const dim3 grid(R, 2), block(bs::kH16Block);
@@ -314,16 +344,23 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         else if (Q == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<2>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
         else if (Q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<4>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
-        hipLaunchKernelGGL(bs::k_prep16, dim3(1), dim3(1024), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
+        ARCHON_HIP_TRY(hipMemsetAsync(&B.prep->big_items, 0, (2 + 256) * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(bs::k_rows_total, dim3(256), dim3(256), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
+        hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep);
         ARCHON_HIP_TRY(hipGetLastError());
-        c->launches += 2;
+        c->launches += 3;
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, &B.prep->big_items, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        e1 = tm.mark();
+        if (speculate) ARCHON_TRY(launch_pass_a(Q, src));
+        if (e1 >= 0) ARCHON_HIP_TRY(hipEventSynchronize(tm.ev[e1]));       // the copy, not the pass behind it
+        else ARCHON_HIP_TRY(hipStreamSynchronize(s));
         *big_items = c->h_mail[0];
         return ARCHON_OK;
     };
     uint32_t big_items = 0;
-    ARCHON_TRY(count16(1, d_x, &big_items));
+    const bool speculate = getenv("ARCHON_SPECULATE") && !getenv("ARCHON_FORCE_PATH");
+    ARCHON_TRY(count16(1, d_x, &big_items, speculate));
+    bool pass_a_done = speculate;
     int path = (uint64_t)big_items * 2 <= n ? 1 : 0;
     if (const char *f = getenv("ARCHON_FORCE_PATH")) path = atoi(f) ? 1 : 0;
     int Q = 1;                                   // symbols per key byte on the streaming path
@@ -355,7 +392,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
                 else if (q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_build_y<4>), grid, block, 0, s, d_x, n, d_lut, B.y);
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_build_y<2>), grid, block, 0, s, d_x, n, d_lut, B.y);
                 ++c->launches;
-                ARCHON_TRY(count16(q, B.y, &big_items));
+                ARCHON_TRY(count16(q, B.y, &big_items, false));
+                pass_a_done = false;
                 if ((uint64_t)big_items * 2 <= n) {
                     path = 1;
                     Q = q;
@@ -365,41 +403,21 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             }
         }
     }
-    const int e1 = tm.mark();
     st.path = (uint32_t)path;
 
-    const uint32_t dbg = getenv("ARCHON_DEBUG") ? (uint32_t)atoi(getenv("ARCHON_DEBUG")) : 0u;   // timing experiments only
     int e2 = e1, e3 = e1, e4 = e1;
     bool need_general = true;
     uint32_t h0 = fwd::kKeyBytes;
     if (path == 1) {
         // ---- streaming first stage: two LSB passes + in-LDS bucket sorts ----
-        uint32_t *A_K = reinterpret_cast<uint32_t *>(B.keyA), *A_I = A_K + n + 8;
         uint32_t *B_K = reinterpret_cast<uint32_t *>(B.keyB), *B_I = B_K + n + 8;
-        uint8_t *A_B1 = reinterpret_cast<uint8_t *>(B.valA);
         bs::TieCtl h_ctl;
         memset(&h_ctl, 0, sizeof h_ctl);
         h_ctl.min_depth = 5;
         h_ctl.base_id = 0xFFFFFFFFu;
         h_ctl.list_cap = kTieListCap;
         ARCHON_HIP_TRY(hipMemcpyAsync(d_ctl, &h_ctl, sizeof h_ctl, hipMemcpyHostToDevice, s));
-        pt.mark();
-        if (Q == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 2>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_y);
-        else if (Q == 4)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_y);
-        else if (Q == 8)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 8>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_y);
-        else if (geo == 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 8, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
-        else if (geo == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
-        else if (geo == 3)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 32, 2>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 16, 4>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
-        pt.mark();
-        ARCHON_HIP_TRY(hipGetLastError());
+        if (!pass_a_done) ARCHON_TRY(launch_pass_a(Q, d_y));
         // pass B has its own tiling of the pass-A output
         const uint32_t ntilesB = div_up(n, tileB);
         uint32_t RB = (uint32_t)kNumCU * wg_per_cu;
@@ -407,7 +425,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         const uint32_t tprB = div_up(ntilesB, RB);
         RB = div_up(ntilesB, tprB);
         hipLaunchKernelGGL(bs::k_range_hist_text, dim3(RB), dim3(bs::kRhBlock), 0, s, A_B1, n, tprB, rhist, 0u, tileB);
-        pt.mark();
+        iB0 = ps.mark();
         unsigned long long *d_stamps = reinterpret_cast<unsigned long long *>(small + 800);
         if (dbg & 4u)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 16, 4, true>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
@@ -424,9 +442,9 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, 4, false>), dim3(RB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
                                B.prep->startB, rhist, dbg, d_stamps, B.prep->startA);
-        pt.mark();
+        iB1 = ps.mark();
         ARCHON_HIP_TRY(hipGetLastError());
-        c->launches += 3;
+        c->launches += 2;
         e2 = tm.mark();
         if (dbg & 8u)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_local_sort<true>), dim3(65536), dim3(bs::kLsBlock), 0, s, B_K, B_I, B.prep->start16, n, sa,
@@ -452,7 +470,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         if (dbg & 4u) {
             unsigned long long hs[8];
             ARCHON_HIP_TRY(hipMemcpy(hs, small + 800, sizeof hs, hipMemcpyDeviceToHost));
-            fprintf(stderr, "pass B stamps (cycles, workgroup 0): load-issue %llu | load-wait %llu | rank %llu | layout %llu | emitK %llu | emitI %llu | - %llu | advance %llu\n",
+            fprintf(stderr, "pass B stamps (cycles, workgroup 0): load-issue %llu | load-wait %llu | rank %llu | layout %llu | emitK %llu | emitI %llu | rank-barrier %llu | advance %llu\n",
                     hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7]);
         }
         if (dbg & 8u) {
@@ -517,13 +535,15 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     st.ms_bwt = need_general ? tm.ms(e4, e5) : 0.f;
     st.ms_total = tm.ms(e0, e5);
     st.kernel_launches = c->launches;
-    for (int i = 0; i + 1 < pt.n; i += 2) {
+    for (int i = 0; i + 1 < pt.n; i += 2) {      // 7-pass route: rs::sort_pairs brackets each pass
         st.ms_radix_pass_sum += pt.ms(i, i + 1);
         ++st.radix_pass_timed;
     }
-    if (path == 1 && pt.n >= 4) {
-        st.ms_pass_text = pt.ms(0, 1);
-        st.ms_pass_rec = pt.ms(2, 3);
+    if (path == 1) {
+        st.ms_pass_text = ps.ms(iA0, iA1);
+        st.ms_pass_rec = ps.ms(iB0, iB1);
+        st.ms_radix_pass_sum = st.ms_pass_text + st.ms_pass_rec;
+        st.radix_pass_timed = 2;
     }
     (void)d_counts; (void)d_starts;
     return ARCHON_OK;
