@@ -36,3 +36,27 @@ def test_inverse_rejects_non_bwt(archon):
         assert base2 == 0 and (b2 == bad).all()
     rc = archon.lib().archon_hip_inverse(ctypes.c_void_p(bad.ctypes.data), 4, 7, ctypes.c_void_p(out.ctypes.data), 0)
     assert rc == archon.E_ARG
+
+
+@pytest.mark.parametrize("slab", ["8", "64"])
+def test_inverse_long_chain_route(archon, oracle, slab, monkeypatch):
+    """the single walk stores each sub-chain in a slab; chains that outgrow it are walked again (k_walk_emit).
+    Tiny slabs make that route carry most of the block."""
+    monkeypatch.setenv("ARCHON_INV_SLAB", slab)
+    for shape, n in (("random", 300001), ("text", 1 << 20), ("a", 70000), ("dna", 123457)):
+        x = S.gen_shape(shape, n)
+        _, B, base = oracle.forward(x)
+        assert (archon.inverse(B, base) == x).all(), (shape, n)
+
+
+def test_inverse_unaligned_device_buffers(archon, oracle):
+    """chain copies start at any byte offset; so may the caller's buffers"""
+    import torch
+    x = S.gen_shape("text", 500003)
+    _, B, base = oracle.forward(x)
+    buf = torch.zeros(x.size + 64, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(x.size + 64, dtype=torch.uint8, device="cuda")
+    for off_in, off_out in ((0, 0), (1, 3), (7, 2), (16, 5)):
+        buf[off_in:off_in + x.size] = torch.from_numpy(B).cuda()
+        archon.inverse_dev(buf[off_in:off_in + x.size], base, out[off_out:off_out + x.size])
+        assert (out[off_out:off_out + x.size].cpu().numpy() == x).all(), (off_in, off_out)
