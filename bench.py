@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--shape", default="random", help="random|dna|text|a|ab|motif (graded config: random)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sa", action="store_true", help="emit BWT only (the metric is quoted WITH the SA)")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the measured configuration) | gloo (rehearsal of the N>1 "
+                    "control flow on fewer GPUs than ranks: ranks share devices, the gather is staged through host memory)")
     args = ap.parse_args()
 
     import torch
@@ -115,8 +117,13 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            local_rank %= max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     if args.gpus != world and rank == 0 and world > 1:
@@ -131,8 +138,9 @@ def main():
     outs = [torch.empty(n + 4, dtype=torch.uint8, device=dev) for _ in range(2)]
     base_t = torch.zeros(1, dtype=torch.int32, device=dev)
     gather_lists = [None, None]
+    gdev = dev if args.backend == "nccl" else torch.device("cpu")
     if dist is not None and rank == 0:
-        gather_lists = [[torch.empty(n + 4, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(2)]
+        gather_lists = [[torch.empty(n + 4, dtype=torch.uint8, device=gdev) for _ in range(world)] for _ in range(2)]
     pending = [None, None]
     pyarchon.reserve(n, local_rank)
 
@@ -153,7 +161,7 @@ def main():
         pass_cnt.append(st["radix_pass_timed"])
         stage.append(st)
         if dist is not None:
-            pending[k] = dist.gather(out_t, gather_lists[k], dst=0, async_op=True)
+            pending[k] = dist.gather(out_t if args.backend == "nccl" else out_t.cpu(), gather_lists[k], dst=0, async_op=True)
 
     def fence():
         for k in range(2):
@@ -174,7 +182,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -182,8 +190,20 @@ def main():
     ok = True
     if sa_t is not None:
         ok = pyarchon.validate_dev(x_t, sa_t)
+    # the exchange step: rank 0 decodes the block it received from the LAST rank (inverse BWT on its own GPU)
+    # and compares with that rank's input, regenerated from the seed -- after the timed region
+    gathered_ok = None
+    if dist is not None and rank == 0:
+        k_last = (step_no[0] - 1) & 1
+        got = gather_lists[k_last][world - 1].to(dev)
+        base_r = int(got[n:].view(torch.int32).item())
+        back = torch.empty(n, dtype=torch.uint8, device=dev)
+        pyarchon.inverse_dev(got[:n], base_r, back)
+        want = torch.from_numpy(archon_synth.gen_shape(args.shape, n, block=world - 1)).to(dev)
+        gathered_ok = bool(torch.equal(back, want))
+        ok = ok and gathered_ok
     if dist is not None:
-        flag = torch.tensor([1 if ok else 0], device=dev)
+        flag = torch.tensor([1 if ok else 0], device=gdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
 
@@ -224,6 +244,7 @@ def main():
                 "parallelism": "block-sharded x%d, one RCCL gather of BWT||baseId per step (async, overlapped with the next step)" % world if world > 1 else "single GPU",
                 "sa_emitted": sa_t is not None,
                 "sa_lf_consistent": ok,
+                "gathered_block_round_trip": gathered_ok,
             },
             "roofline": {
                 "bound": "hbm",

@@ -129,3 +129,22 @@ def test_container_rejects_plain_file(archon, tmp_path):
     p.write_bytes(b"not a container at all")
     r = subprocess.run([EXE, "d", "-b", str(p), str(tmp_path / "o")], capture_output=True, text=True)
     assert r.returncode != 0
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py's N>1 control flow (double-buffered async gather, barriers, max-over-ranks clock, decode of the
+    block gathered from the last rank) with 2 ranks sharing this one GPU over gloo.  Not a measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--block-mib", "8", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=280, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["blocks_per_step"] == 2
+    assert line["config"]["sa_lf_consistent"] is True and line["config"]["gathered_block_round_trip"] is True
+    assert line["value"] > 0 and "roofline" in line and "cpu_baseline" not in line
