@@ -20,3 +20,4 @@ for sh in random dna text a ab motif; do
 done
 timeout -k 10 120 python3 tools/stage_times.py 256 random 3 inv 2>/dev/null | tail -1 | sed "s/^/inverse-random /" >> $out/stage_times.txt
 cat $out/stage_times.txt
+timeout -k 10 600 python3 tools/config5.py 256 2>/dev/null | tail -1 > $out/config5.json && cat $out/config5.json
