@@ -311,32 +311,11 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     uint32_t *A_K = reinterpret_cast<uint32_t *>(B.keyA), *A_I = A_K + n + 8;
     uint8_t *A_B1 = reinterpret_cast<uint8_t *>(B.valA);
     const uint32_t dbg = getenv("ARCHON_DEBUG") ? (uint32_t)atoi(getenv("ARCHON_DEBUG")) : 0u;   // timing experiments only
-    auto launch_pass_a = [&](int Q, const uint8_t *key_text) -> int {
-        iA0 = ps.mark();
-        if (Q == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 2>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, key_text);
-        else if (Q == 4)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, key_text);
-        else if (Q == 8)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 8>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, key_text);
-        else if (geo == 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 8, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
-        else if (geo == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
-        else if (geo == 3)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 32, 2>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 16, 4>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x);
-        iA1 = ps.mark();
-        ARCHON_HIP_TRY(hipGetLastError());
-        ++c->launches;
-        return ARCHON_OK;
-    };
-    // The two-byte count decides the route, and the host has to see it.  ARCHON_SPECULATE=1 queues pass A of the
-    // streaming stage BEFORE the host waits; measured: the round trip costs < 0.03 ms per block while a block that
-    // turns out skewed pays a wasted pass (1.3-1.8 ms per 256 MiB on DNA / text), so it is off by default.
+    // The two-byte count decides the route.  The host does not wait for it: the count leaves a `skip` flag on the
+    // device, the whole streaming stage is queued behind it, and its kernels return at once when the flag says
+    // "skewed".  One host round trip per block (after k_resolve_ties) instead of two.
     int e1 = -1;
-    auto count16 = [&](int Q, const uint8_t *src, uint32_t *big_items, bool speculate) -> int {
+    auto count16 = [&](int Q, const uint8_t *src, bool force_stream) -> int {
         ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, 65536 * sizeof(uint32_t), s));
         ARCHON_HIP_TRY(hipMemsetAsync(rhist, 0, (size_t)R * 256 * sizeof(uint32_t), s));
         const dim3 grid(R, 2), block(bs::kH16Block);
@@ -346,25 +325,104 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
         ARCHON_HIP_TRY(hipMemsetAsync(&B.prep->big_items, 0, (2 + 256) * sizeof(uint32_t), s));
         hipLaunchKernelGGL(bs::k_rows_total, dim3(256), dim3(256), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
-        hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep);
+        hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep, force_stream ? 1u : 0u);
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 3;
-        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, &B.prep->big_items, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         e1 = tm.mark();
-        if (speculate) ARCHON_TRY(launch_pass_a(Q, src));
-        if (e1 >= 0) ARCHON_HIP_TRY(hipEventSynchronize(tm.ev[e1]));       // the copy, not the pass behind it
-        else ARCHON_HIP_TRY(hipStreamSynchronize(s));
-        *big_items = c->h_mail[0];
         return ARCHON_OK;
     };
+    int e2 = -1, e2b = -1, e3 = -1, e4 = -1;
+    bs::TieCtl h_ctl;
     uint32_t big_items = 0;
-    const bool speculate = getenv("ARCHON_SPECULATE") && !getenv("ARCHON_FORCE_PATH");
-    ARCHON_TRY(count16(1, d_x, &big_items, speculate));
-    bool pass_a_done = speculate;
-    int path = (uint64_t)big_items * 2 <= n ? 1 : 0;
-    if (const char *f = getenv("ARCHON_FORCE_PATH")) path = atoi(f) ? 1 : 0;
+    uint32_t *B_K = reinterpret_cast<uint32_t *>(B.keyB), *B_I = B_K + n + 8;
+    const uint32_t *d_skip = &B.prep->skip;
+    // ---- streaming first stage: two LSB passes + in-LDS bucket sorts; ends with the block's host round trip ----
+    auto streaming = [&](int Q, const uint8_t *key_text) -> int {
+        memset(&h_ctl, 0, sizeof h_ctl);
+        h_ctl.min_depth = 5;
+        h_ctl.base_id = 0xFFFFFFFFu;
+        h_ctl.list_cap = kTieListCap;
+        memcpy(c->h_mail + 2048, &h_ctl, sizeof h_ctl);           // pinned staging: the upload does not block
+        ARCHON_HIP_TRY(hipMemcpyAsync(d_ctl, c->h_mail + 2048, sizeof h_ctl, hipMemcpyHostToDevice, s));
+        iA0 = ps.mark();
+        if (Q == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 2>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, key_text, d_skip);
+        else if (Q == 4)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, key_text, d_skip);
+        else if (Q == 8)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 8>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, key_text, d_skip);
+        else if (geo == 1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 8, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x, d_skip);
+        else if (geo == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x, d_skip);
+        else if (geo == 3)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 32, 2>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x, d_skip);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 16, 4>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x, d_skip);
+        iA1 = ps.mark();
+        // pass B has its own tiling of the pass-A output
+        const uint32_t ntilesB = div_up(n, tileB);
+        uint32_t RB = (uint32_t)kNumCU * wg_per_cu;
+        if (RB > ntilesB) RB = ntilesB;
+        const uint32_t tprB = div_up(ntilesB, RB);
+        RB = div_up(ntilesB, tprB);
+        hipLaunchKernelGGL(bs::k_range_hist_text, dim3(RB), dim3(bs::kRhBlock), 0, s, A_B1, n, tprB, rhist, 0u, tileB, d_skip);
+        iB0 = ps.mark();
+        unsigned long long *d_stamps = reinterpret_cast<unsigned long long *>(small + 800);
+        if (dbg & 4u)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 16, 4, true>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
+                               B.prep->startB, rhist, dbg & 1u, d_stamps, B.prep->startA, d_skip);
+        else if (geo == 1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 8, 4, false>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
+                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip);
+        else if (geo == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 16, 4, false>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
+                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip);
+        else if (geo == 3)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 32, 2, false>), dim3(RB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
+                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, 4, false>), dim3(RB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
+                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip);
+        iB1 = ps.mark();
+        e2 = tm.mark();
+        if (dbg & 8u)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_local_sort<true>), dim3(65536), dim3(bs::kLsBlock), 0, s, B_K, B_I, B.prep->start16, n, sa,
+                               d_bwt, d_ctl, B.tie_list, reinterpret_cast<unsigned long long *>(small + 820), d_skip);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_local_sort<false>), dim3(65536), dim3(bs::kLsBlock), 0, s, B_K, B_I, B.prep->start16, n, sa,
+                               d_bwt, d_ctl, B.tie_list, reinterpret_cast<unsigned long long *>(small + 820), d_skip);
+        e2b = tm.mark();
+        hipLaunchKernelGGL(bs::k_resolve_ties, dim3(div_up(kTieListCap, 256)), dim3(256), 0, s, d_x, n, B.tie_list, d_ctl,
+                           sa, d_bwt, 5u * (uint32_t)Q, 64u * (uint32_t)Q, d_skip);
+        ARCHON_HIP_TRY(hipGetLastError());
+        c->launches += 6;
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_ctl, sizeof(bs::TieCtl), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 64, &B.prep->big_items, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        e3 = tm.mark();
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        memcpy(&h_ctl, c->h_mail, sizeof h_ctl);
+        big_items = c->h_mail[64];
+        return ARCHON_OK;
+    };
+    auto count_wait = [&]() -> int {             // routes that need the count on the host before going on
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 64, &B.prep->big_items, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        big_items = c->h_mail[64];
+        return ARCHON_OK;
+    };
+    int forced = -1;
+    if (const char *f = getenv("ARCHON_FORCE_PATH")) forced = atoi(f) ? 1 : 0;
+    int path;
     int Q = 1;                                   // symbols per key byte on the streaming path
-    const uint8_t *d_y = d_x;                    // its key text
+    ARCHON_TRY(count16(1, d_x, forced == 1));
+    if (forced == 0) {
+        ARCHON_TRY(count_wait());
+        path = 0;
+    } else {
+        ARCHON_TRY(streaming(1, d_x));
+        path = (forced == 1 || (uint64_t)big_items * 2 <= n) ? 1 : 0;
+    }
     uint32_t sigma = 0, bits = 8;
     uint8_t *d_lut = reinterpret_cast<uint8_t *>(small + 900);
     if (path == 0) {
@@ -384,85 +442,33 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         if (sigma <= 16 && !getenv("ARCHON_NO_PACK")) {
             memcpy(c->h_mail + 1024, h_lut, 256);
             ARCHON_HIP_TRY(hipMemcpyAsync(d_lut, c->h_mail + 1024, 256, hipMemcpyHostToDevice, s));
-            ARCHON_HIP_TRY(hipStreamSynchronize(s));          // h_mail is reused below
-            if (sigma >= 2 && geo == 2 && !getenv("ARCHON_FORCE_PATH") && !getenv("ARCHON_NO_PACK_STREAM")) {
+            if (sigma >= 2 && geo == 2 && forced < 0 && !getenv("ARCHON_NO_PACK_STREAM")) {
                 const int q = bits == 1 ? 8 : bits == 2 ? 4 : 2;
                 const dim3 grid(div_up(div_up(n, 4), 256)), block(256);
                 if (q == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_build_y<8>), grid, block, 0, s, d_x, n, d_lut, B.y);
                 else if (q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_build_y<4>), grid, block, 0, s, d_x, n, d_lut, B.y);
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_build_y<2>), grid, block, 0, s, d_x, n, d_lut, B.y);
                 ++c->launches;
-                ARCHON_TRY(count16(q, B.y, &big_items, false));
-                pass_a_done = false;
+                ARCHON_TRY(count16(q, B.y, false));
+                ARCHON_TRY(streaming(q, B.y));
                 if ((uint64_t)big_items * 2 <= n) {
                     path = 1;
                     Q = q;
-                    d_y = B.y;
                     st.alphabet_bits = 8 / q;
                 }
             }
+            ARCHON_HIP_TRY(hipStreamSynchronize(s));          // the table upload has left h_mail
         }
     }
     st.path = (uint32_t)path;
 
-    int e2 = e1, e3 = e1, e4 = e1;
+    if (e2 < 0) e2 = e1;
+    if (e3 < 0) e3 = e1;
+    e4 = e1;
     bool need_general = true;
     uint32_t h0 = fwd::kKeyBytes;
     if (path == 1) {
-        // ---- streaming first stage: two LSB passes + in-LDS bucket sorts ----
-        uint32_t *B_K = reinterpret_cast<uint32_t *>(B.keyB), *B_I = B_K + n + 8;
-        bs::TieCtl h_ctl;
-        memset(&h_ctl, 0, sizeof h_ctl);
-        h_ctl.min_depth = 5;
-        h_ctl.base_id = 0xFFFFFFFFu;
-        h_ctl.list_cap = kTieListCap;
-        ARCHON_HIP_TRY(hipMemcpyAsync(d_ctl, &h_ctl, sizeof h_ctl, hipMemcpyHostToDevice, s));
-        if (!pass_a_done) ARCHON_TRY(launch_pass_a(Q, d_y));
-        // pass B has its own tiling of the pass-A output
-        const uint32_t ntilesB = div_up(n, tileB);
-        uint32_t RB = (uint32_t)kNumCU * wg_per_cu;
-        if (RB > ntilesB) RB = ntilesB;
-        const uint32_t tprB = div_up(ntilesB, RB);
-        RB = div_up(ntilesB, tprB);
-        hipLaunchKernelGGL(bs::k_range_hist_text, dim3(RB), dim3(bs::kRhBlock), 0, s, A_B1, n, tprB, rhist, 0u, tileB);
-        iB0 = ps.mark();
-        unsigned long long *d_stamps = reinterpret_cast<unsigned long long *>(small + 800);
-        if (dbg & 4u)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 16, 4, true>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg & 1u, d_stamps, B.prep->startA);
-        else if (geo == 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 8, 4, false>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA);
-        else if (geo == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 16, 4, false>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA);
-        else if (geo == 3)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 32, 2, false>), dim3(RB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, 4, false>), dim3(RB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA);
-        iB1 = ps.mark();
-        ARCHON_HIP_TRY(hipGetLastError());
-        c->launches += 2;
-        e2 = tm.mark();
-        if (dbg & 8u)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_local_sort<true>), dim3(65536), dim3(bs::kLsBlock), 0, s, B_K, B_I, B.prep->start16, n, sa,
-                               d_bwt, d_ctl, B.tie_list, reinterpret_cast<unsigned long long *>(small + 820));
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_local_sort<false>), dim3(65536), dim3(bs::kLsBlock), 0, s, B_K, B_I, B.prep->start16, n, sa,
-                               d_bwt, d_ctl, B.tie_list, reinterpret_cast<unsigned long long *>(small + 820));
-        ARCHON_HIP_TRY(hipGetLastError());
-        const int e2b = tm.mark();
-        hipLaunchKernelGGL(bs::k_resolve_ties, dim3(div_up(kTieListCap, 256)), dim3(256), 0, s, d_x, n, B.tie_list, d_ctl,
-                           sa, d_bwt, 5u * (uint32_t)Q, 64u * (uint32_t)Q);
-        ARCHON_HIP_TRY(hipGetLastError());
-        c->launches += 4;
         st.radix_passes = 2;
-        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_ctl, sizeof(bs::TieCtl), hipMemcpyDeviceToHost, s));
-        e3 = tm.mark();
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
-        memcpy(&h_ctl, c->h_mail, sizeof h_ctl);
         st.tie_groups = h_ctl.tie_groups;
         st.tie_items = h_ctl.tie_items;
         st.ms_local_sort = tm.ms(e2, e2b);
