@@ -351,6 +351,9 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, key_text, d_skip);
         else if (Q == 8)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 8>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, key_text, d_skip);
+        else if (dbg & 16u)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 1, true>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, 0u, d_x, d_skip,
+                               reinterpret_cast<unsigned long long *>(small + 840));
         else if (geo == 1)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 8, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x, d_skip);
         else if (geo == 2)
@@ -473,6 +476,12 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         st.tie_items = h_ctl.tie_items;
         st.ms_local_sort = tm.ms(e2, e2b);
         st.ms_resolve = tm.ms(e2b, e3);
+        if (dbg & 16u) {
+            unsigned long long hs[8];
+            ARCHON_HIP_TRY(hipMemcpy(hs, small + 840, sizeof hs, hipMemcpyDeviceToHost));
+            fprintf(stderr, "pass A stamps (cycles, workgroup 0): load+keys %llu | rank %llu | rank-barrier %llu | layout %llu | emitK %llu | emitIB %llu | advance %llu\n",
+                    hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6]);
+        }
         if (dbg & 4u) {
             unsigned long long hs[8];
             ARCHON_HIP_TRY(hipMemcpy(hs, small + 800, sizeof hs, hipMemcpyDeviceToHost));
