@@ -274,3 +274,31 @@ def test_compacted_alphabet_with_repeats(archon, oracle):
     assert (sa == P).all()
     assert (bwt == B).all() and base == b0
     assert st["path"] == 1 and st["alphabet_bits"] == 2 and st["doubling_rounds"] > 0
+
+
+@pytest.mark.parametrize("shape", ["random", "a"])
+def test_max_block(archon, shape):
+    """the largest block the boundary accepts (MAX_N = 0x3FFFFF00 bytes, just under 1 GiB; the reference's own
+    tracking path needs N < 2^30, archon.cpp:802): size-independent properties, device-resident buffers."""
+    import torch
+    n = archon.MAX_N
+    x = S.gen_random(n) if shape == "random" else np.full(n, 97, np.uint8)
+    x_t = torch.from_numpy(x).cuda()
+    del x
+    sa_t = torch.empty(n, dtype=torch.int32, device="cuda")
+    bwt_t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    base_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+    archon.forward_dev(x_t, sa_t, bwt_t, base_t)
+    st = archon.stats()
+    # beyond ~300 MB the two-byte buckets of even a uniform block exceed the in-LDS sort (4608 items): 7-pass route
+    assert st["path"] == 0
+    base = int(base_t.item())
+    assert int(sa_t[base].item()) == n
+    if shape == "a":      # a^N: the order is N, N-1, ..., 1
+        assert torch.equal(sa_t, torch.arange(n, 0, -1, dtype=torch.int32, device="cuda")) and base == 0
+        assert st["doubling_rounds"] == 0 and st["period"] == 1
+    assert archon.validate_dev(x_t, sa_t)
+    del sa_t
+    out_t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    archon.inverse_dev(bwt_t, base, out_t)
+    assert torch.equal(out_t, x_t)
