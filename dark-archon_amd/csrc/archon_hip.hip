@@ -818,6 +818,75 @@ int archon_hip_validate(const uint8_t *x, uint32_t n, const uint32_t *sa, int de
     return rc;
 }
 
+static int sa_to_bwt_run(Ctx *c, hipStream_t s, const uint8_t *d_x, uint32_t n, const uint32_t *d_sa, uint8_t *d_bwt,
+                         uint32_t *d_base_out)
+{
+    uint32_t *res = c->d_mail + 600;            // [0] bad value seen, [1] rows holding n, [2] the primary index
+    ARCHON_HIP_TRY(hipMemsetAsync(res, 0, 3 * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(fwd::k_sa_to_bwt, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, d_sa, n, d_bwt, res + 2, res);
+    ARCHON_HIP_TRY(hipGetLastError());
+    ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, res, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    if (c->h_mail[0] || c->h_mail[1] != 1) {
+        set_error("not a suffix array in a7 order: %s", c->h_mail[0] ? "values outside 1..n" : "no single row holds n");
+        return ARCHON_E_CORRUPT;
+    }
+    ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, res + 2, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    return ARCHON_OK;
+}
+
+int archon_hip_sa_to_bwt_dev(const uint8_t *d_x, uint32_t n, const uint32_t *d_sa, uint8_t *d_bwt, uint32_t *d_base_id,
+                             int dev, void *stream)
+{
+    if (!d_x || !d_sa || !d_bwt || !d_base_id) { set_error("null pointer"); return ARCHON_E_ARG; }
+    ARCHON_TRY(check_n(n));
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+    return sa_to_bwt_run(c, s, d_x, n, d_sa, d_bwt, d_base_id);
+}
+
+int archon_hip_sa_to_bwt(const uint8_t *x, uint32_t n, const uint32_t *sa, uint8_t *bwt, uint32_t *base_id, int dev)
+{
+    if (!x || !sa || !bwt || !base_id) { set_error("null pointer"); return ARCHON_E_ARG; }
+    ARCHON_TRY(check_n(n));
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = c->own_stream;
+    uint8_t *d_x = nullptr, *d_bwt = nullptr;
+    uint32_t *d_sa = nullptr;
+    int rc = ARCHON_E_NOMEM;
+    if (hipMalloc((void **)&d_x, (size_t)n + 64) == hipSuccess && hipMalloc((void **)&d_bwt, (size_t)n + 64) == hipSuccess &&
+        hipMalloc((void **)&d_sa, (size_t)n * 4 + 64) == hipSuccess) {
+        rc = ARCHON_E_HIP;
+        if (hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s) == hipSuccess &&
+            hipMemcpyAsync(d_sa, sa, (size_t)n * 4, hipMemcpyHostToDevice, s) == hipSuccess) {
+            rc = sa_to_bwt_run(c, s, d_x, n, d_sa, d_bwt, c->d_mail + 610);
+            if (rc == ARCHON_OK &&
+                (hipMemcpyAsync(bwt, d_bwt, n, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                 hipMemcpyAsync(base_id, c->d_mail + 610, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                 hipStreamSynchronize(s) != hipSuccess)) {
+                set_error("HIP copy failed");
+                rc = ARCHON_E_HIP;
+            }
+        } else {
+            set_error("HIP copy failed");
+        }
+    } else {
+        (void)hipGetLastError();
+        set_error("device allocation failed");
+    }
+    if (d_x) (void)hipFree(d_x);
+    if (d_bwt) (void)hipFree(d_bwt);
+    if (d_sa) (void)hipFree(d_sa);
+    return rc;
+}
+
 int archon_hip_radix_scatter_dev(const uint8_t *d_src, size_t n, uint8_t *d_dst, int dev, void *stream)
 {
     if (!d_src || !d_dst) { set_error("null pointer"); return ARCHON_E_ARG; }

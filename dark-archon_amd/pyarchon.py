@@ -23,7 +23,7 @@ SYMBOLS = [
     "archon_hip_validate", "archon_hip_radix_scatter",
     "archon_hip_forward_keep", "archon_hip_read_bwt", "archon_hip_host_alloc", "archon_hip_host_free",
     "archon_hip_forward_dev", "archon_hip_inverse_dev", "archon_hip_hist256_dev",
-    "archon_hip_validate_dev", "archon_hip_radix_scatter_dev",
+    "archon_hip_validate_dev", "archon_hip_radix_scatter_dev", "archon_hip_sa_to_bwt", "archon_hip_sa_to_bwt_dev",
     "archon_hip_reserve", "archon_hip_release", "archon_hip_get_stats",
 ]
 
@@ -66,6 +66,8 @@ def load():
         "archon_hip_inverse": [vp, u32, u32, vp, i32],
         "archon_hip_hist256": [vp, sz, vp, i32],
         "archon_hip_validate": [vp, u32, vp, i32],
+        "archon_hip_sa_to_bwt": [vp, u32, vp, vp, vp, i32],
+        "archon_hip_sa_to_bwt_dev": [vp, u32, vp, vp, vp, i32, vp],
         "archon_hip_radix_scatter": [vp, sz, vp, i32],
         "archon_hip_forward_dev": [vp, u32, vp, vp, vp, i32, vp],
         "archon_hip_inverse_dev": [vp, u32, u32, vp, i32, vp],
@@ -138,6 +140,16 @@ def validate(x, sa, dev=0):
     x = np.ascontiguousarray(x, dtype=np.uint8)
     sa = np.ascontiguousarray(sa, dtype=np.uint32)
     return bool(_check(lib().archon_hip_validate(_p(x), x.size, _p(sa), dev)))
+
+
+def sa_to_bwt(x, sa, dev=0):
+    """(bwt, base_id) for a suffix array the caller holds (Archon::enWrite's gather, archon.cpp:887-900)"""
+    x = np.ascontiguousarray(x, dtype=np.uint8)
+    sa = np.ascontiguousarray(sa, dtype=np.uint32)
+    bwt = np.empty(x.size, np.uint8)
+    base = ctypes.c_uint32(0)
+    _check(lib().archon_hip_sa_to_bwt(_p(x), x.size, _p(sa), _p(bwt), ctypes.byref(base), dev))
+    return bwt, int(base.value)
 
 
 def radix_scatter(src, dev=0):

@@ -10,6 +10,7 @@
  *   archon_hip_inverse      Archon::deCompute (917-935) + the LF walk of Archon::deWrite (937-943)
  *   archon_hip_hist256      Constructor::makeBuckets (118-126); tool/radix_dir/radix.c:31-36
  *   archon_hip_validate     Archon::validate (862-874)
+ *   archon_hip_sa_to_bwt    the gather loop of Archon::enWrite alone (887-900), for a caller's own SA
  *   archon_hip_radix_scatter  the counting-sort scatter of tool/radix_dir/radix.c:40-44
  *
  * Ordering convention ("a7 order"): item s in 1..N names the
@@ -81,6 +82,11 @@ int archon_hip_hist256(const uint8_t *x, size_t n, uint32_t out[256], int dev);
 /* LF-consistency of sa against x; returns 1 = consistent, 0 = not, <0 = error. */
 int archon_hip_validate(const uint8_t *x, uint32_t n, const uint32_t *sa, int dev);
 
+/* SA -> BWT + primary index for a suffix array the caller already holds (Archon::enWrite, archon.cpp:887-900):
+ * bwt[i] = x[sa[i]] (x[0] where sa[i]==n), *base_id = the row holding n.  ARCHON_E_CORRUPT when sa holds a value
+ * outside 1..n or not exactly one n. */
+int archon_hip_sa_to_bwt(const uint8_t *x, uint32_t n, const uint32_t *sa, uint8_t *bwt, uint32_t *base_id, int dev);
+
 /* dst = src stably sorted by byte value (tool/radix_dir scatter), host pointers. */
 int archon_hip_radix_scatter(const uint8_t *src, size_t n, uint8_t *dst, int dev);
 
@@ -96,6 +102,8 @@ int archon_hip_inverse_dev(const uint8_t *d_bwt, uint32_t n, uint32_t base_id,
                            uint8_t *d_x_out, int dev, void *stream);
 int archon_hip_hist256_dev(const uint8_t *d_x, size_t n, uint32_t *d_out256, int dev, void *stream);
 int archon_hip_validate_dev(const uint8_t *d_x, uint32_t n, const uint32_t *d_sa, int dev, void *stream);
+int archon_hip_sa_to_bwt_dev(const uint8_t *d_x, uint32_t n, const uint32_t *d_sa, uint8_t *d_bwt, uint32_t *d_base_id,
+                             int dev, void *stream);
 int archon_hip_radix_scatter_dev(const uint8_t *d_src, size_t n, uint8_t *d_dst, int dev, void *stream);
 
 /* ---- workspace / lifetime ---------------------------------------------------- */

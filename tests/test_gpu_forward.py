@@ -302,3 +302,18 @@ def test_max_block(archon, shape):
     out_t = torch.empty(n, dtype=torch.uint8, device="cuda")
     archon.inverse_dev(bwt_t, base, out_t)
     assert torch.equal(out_t, x_t)
+
+
+def test_sa_to_bwt_standalone(archon, oracle):
+    """A7 on its own (Archon::enWrite's gather): BWT + primary index from a caller's SA; foreign SAs are rejected."""
+    for shape, n in (("text", 100003), ("random", 1 << 20), ("a", 777)):
+        x = S.gen_shape(shape, n)
+        P, B, b0 = oracle.forward(x)
+        bwt, base = archon.sa_to_bwt(x, P)
+        assert (bwt == B).all() and base == b0
+    x = S.gen_text(1000)
+    P, _, _ = oracle.forward(x)
+    for bad in (np.where(P == 1000, 999, P), np.where(P == 5, 0, P), np.where(P == 7, 1001, P)):
+        with pytest.raises(archon.ArchonError) as e:
+            archon.sa_to_bwt(x, bad.astype(np.uint32))
+        assert e.value.code == archon.E_CORRUPT
