@@ -286,8 +286,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     uint32_t *sa = d_sa_user ? d_sa_user : B.sa_own;
     const uint32_t g256 = div_up(n, 256);
 
-    StageTimer tm(s);
-    StageTimer pt(s);
+    StageTimer tm(c, 0, s);
+    StageTimer pt(c, 24, s);
     const int e0 = tm.mark();
 
     // A2 / bucket setup: the two-byte count (a4 compute(), archon.c:146-161) and its scans.  The count
@@ -306,7 +306,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     R = div_up(ntiles, tpr);
     uint32_t *rhist = B.sc.d_status;            // [R][256], reused by both passes
     // Q = symbols per key byte of the streaming stage: 1 = plain bytes; 2/4/8 = compacted alphabet (below)
-    StageTimer ps(s);                            // streaming stage: pass A, pass B (their own HIP events)
+    StageTimer ps(c, 48, s);                            // streaming stage: pass A, pass B (their own HIP events)
     int iA0 = -1, iA1 = -1, iB0 = -1, iB1 = -1;
     uint32_t *A_K = reinterpret_cast<uint32_t *>(B.keyA), *A_I = A_K + n + 8;
     uint8_t *A_B1 = reinterpret_cast<uint8_t *>(B.valA);
@@ -956,6 +956,8 @@ int archon_hip_release(int dev)
         if (c->keep_bwt) (void)hipFree(c->keep_bwt);
         if (c->d_mail) (void)hipFree(c->d_mail);
         if (c->h_mail) (void)hipHostFree(c->h_mail);
+        for (int i = 0; i < Ctx::kEvents; ++i)
+            if (c->ev_pool[i]) (void)hipEventDestroy(c->ev_pool[i]);
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     }
     delete c;
