@@ -314,6 +314,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // The two-byte count decides the route.  The host does not wait for it: the count leaves a `skip` flag on the
     // device, the whole streaming stage is queued behind it, and its kernels return at once when the flag says
     // "skewed".  One host round trip per block (after k_resolve_ties) instead of two.
+    // bucket-per-workgroup pass B (Prep::aligned) needs 256 workgroups and enough tiles per bucket to matter
+    const uint32_t allow_aligned = (geo == 2 && n >= (1u << 24) && !getenv("ARCHON_NO_ALIGNED")) ? 1u : 0u;
     int e1 = -1;
     auto count16 = [&](int Q, const uint8_t *src, bool force_stream) -> int {
         ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, 65536 * sizeof(uint32_t), s));
@@ -325,7 +327,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
         ARCHON_HIP_TRY(hipMemsetAsync(&B.prep->big_items, 0, (2 + 256) * sizeof(uint32_t), s));
         hipLaunchKernelGGL(bs::k_rows_total, dim3(256), dim3(256), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
-        hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep, force_stream ? 1u : 0u);
+        hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep, force_stream ? 1u : 0u, allow_aligned);
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 3;
         e1 = tm.mark();
@@ -369,24 +371,25 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         if (RB > ntilesB) RB = ntilesB;
         const uint32_t tprB = div_up(ntilesB, RB);
         RB = div_up(ntilesB, tprB);
+        const uint32_t gridB = allow_aligned ? 256u : RB;      // surplus workgroups of the range mode return at once
         hipLaunchKernelGGL(bs::k_range_hist_text, dim3(RB), dim3(bs::kRhBlock), 0, s, A_B1, n, tprB, rhist, 0u, tileB, d_skip);
         iB0 = ps.mark();
         unsigned long long *d_stamps = reinterpret_cast<unsigned long long *>(small + 800);
         if (dbg & 4u)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 16, 4, true>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg & 1u, d_stamps, B.prep->startA, d_skip);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 16, 4, true>), dim3(gridB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
+                               B.prep->startB, rhist, dbg & 1u, d_stamps, B.prep->startA, d_skip, B.prep->start16);
         else if (geo == 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 8, 4, false>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 8, 4, false>), dim3(gridB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
+                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip, B.prep->start16);
         else if (geo == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 16, 4, false>), dim3(RB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 16, 4, false>), dim3(gridB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
+                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip, B.prep->start16);
         else if (geo == 3)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 32, 2, false>), dim3(RB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 32, 2, false>), dim3(gridB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
+                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip, B.prep->start16);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, 4, false>), dim3(RB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, 4, false>), dim3(gridB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
+                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip, B.prep->start16);
         iB1 = ps.mark();
         e2 = tm.mark();
         if (dbg & 8u)

@@ -317,3 +317,39 @@ def test_sa_to_bwt_standalone(archon, oracle):
         with pytest.raises(archon.ArchonError) as e:
             archon.sa_to_bwt(x, bad.astype(np.uint32))
         assert e.value.code == archon.E_CORRUPT
+
+
+def test_pass_b_bucket_mode_matches_range_mode(archon, oracle, monkeypatch):
+    """pass B deals whole second-byte buckets to workgroups when they are balanced (n >= 16 Mi), equal tile ranges
+    otherwise: both must give the oracle's SA, also on a block whose buckets are balanced but not uniform."""
+    rng = np.random.default_rng(12)
+    n = (1 << 24) + 12345
+    x_uniform = S.gen_random(n)
+    # second bytes balanced (every value equally often), first bytes skewed towards small values
+    x_mixed = np.where(np.arange(n) % 2 == 0, rng.integers(0, 256, n), np.minimum(rng.integers(0, 256, n), rng.integers(0, 256, n))).astype(np.uint8)
+    for x in (x_uniform, x_mixed):
+        P = oracle.sa(x)
+        sa, bwt, base = archon.forward(x)
+        assert (sa == P).all()
+        monkeypatch.setenv("ARCHON_NO_ALIGNED", "1")
+        sa2, bwt2, base2 = archon.forward(x)
+        monkeypatch.delenv("ARCHON_NO_ALIGNED")
+        assert (sa2 == P).all() and (bwt2 == bwt).all() and base2 == base
+
+
+@pytest.mark.parametrize("shape", ["random", "dna"])
+@pytest.mark.parametrize("n", [1 << 24, (1 << 24) + 1, 23456789, (1 << 25) + 16383, 100000007])
+def test_mid_sizes_lf_consistent(archon, shape, n):
+    """block sizes between the oracle-checked ones and the full block, tile counts that do not divide evenly among
+    the 256 workgroups, bucket mode of pass B on byte and on recoded (2-bit) keys: LF-consistency + round trip"""
+    import torch
+    x_t = torch.from_numpy(S.gen_shape(shape, n)).cuda()
+    sa_t = torch.empty(n, dtype=torch.int32, device="cuda")
+    bwt_t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    base_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+    archon.forward_dev(x_t, sa_t, bwt_t, base_t)
+    assert archon.stats()["path"] == 1
+    assert archon.validate_dev(x_t, sa_t)
+    out_t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    archon.inverse_dev(bwt_t, int(base_t.item()), out_t)
+    assert torch.equal(out_t, x_t)
