@@ -103,6 +103,7 @@ static size_t forward_arena_bytes(uint32_t n)
     add(4 * rs::status_words(n));
     add(4 * 8 * 256); add(4 * 8 * 256);       // ghist, gstart
     add(4 * 65536);                           // hist16
+    add(4 * (size_t)bs::kMaxRanges * 256);    // range table of the passes
     add(sizeof(bs::Prep));
     add(sizeof(uint2) * kTieListCap);
     add(4 * 1024);                            // counts, starts, ticket, err, base, totals, TieCtl
@@ -113,7 +114,7 @@ struct FwdBuf {
     uint8_t *xa;
     uint64_t *keyA, *keyB;
     uint32_t *valA, *valB, *rank, *sa_own, *v, *keep, *dst;
-    uint32_t *upos[2], *ug[2], *uitem[2], *uinit;
+    uint32_t *upos[2], *ug[2], *uitem[2], *uinit, *rhist;
     uint8_t *y;
     uint32_t *scan_tmp, *hist16, *small;
     bs::Prep *prep;
@@ -261,8 +262,9 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     B.sc.d_status = c->alloc<uint32_t>(rs::status_words(n));
     B.sc.d_ghist = c->alloc<uint32_t>(8 * 256);
     B.sc.d_gstart = c->alloc<uint32_t>(8 * 256);
-    B.hist16 = c->alloc<uint32_t>(65536);
-    B.prep = c->alloc<bs::Prep>(1);
+    B.hist16 = c->alloc<uint32_t>(65536);                       // } contiguous: zeroed by ONE memset per count
+    B.rhist = c->alloc<uint32_t>((size_t)bs::kMaxRanges * 256);  // } (hist16, range table, the counters that
+    B.prep = c->alloc<bs::Prep>(1);                             // }  open Prep)
     B.tie_list = c->alloc<uint2>(kTieListCap);
     B.small = c->alloc<uint32_t>(1024);
     if (!B.small) {
@@ -304,7 +306,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     if (R > ntiles) R = ntiles;
     const uint32_t tpr = div_up(ntiles, R);
     R = div_up(ntiles, tpr);
-    uint32_t *rhist = B.sc.d_status;            // [R][256], reused by both passes
+    uint32_t *rhist = B.rhist;                  // [R][256], reused by both passes
     // Q = symbols per key byte of the streaming stage: 1 = plain bytes; 2/4/8 = compacted alphabet (below)
     StageTimer ps(c, 48, s);                            // streaming stage: pass A, pass B (their own HIP events)
     int iA0 = -1, iA1 = -1, iB0 = -1, iB1 = -1;
@@ -318,16 +320,14 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     const uint32_t allow_aligned = (geo == 2 && n >= (1u << 24) && !getenv("ARCHON_NO_ALIGNED")) ? 1u : 0u;
     int e1 = -1;
     auto count16 = [&](int Q, const uint8_t *src, bool force_stream) -> int {
-        ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, 65536 * sizeof(uint32_t), s));
-        ARCHON_HIP_TRY(hipMemsetAsync(rhist, 0, (size_t)R * 256 * sizeof(uint32_t), s));
+        ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, (size_t)(reinterpret_cast<char *>(&B.prep->cntA[256]) - reinterpret_cast<char *>(B.hist16)), s));
         const dim3 grid(R, 2), block(bs::kH16Block);
         if (Q == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<1>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
         else if (Q == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<2>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
         else if (Q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<4>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
-        ARCHON_HIP_TRY(hipMemsetAsync(&B.prep->big_items, 0, (2 + 256) * sizeof(uint32_t), s));
         hipLaunchKernelGGL(bs::k_rows_total, dim3(256), dim3(256), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
-        hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep, force_stream ? 1u : 0u, allow_aligned);
+        hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep, force_stream ? 1u : 0u, allow_aligned, d_ctl, (uint32_t)kTieListCap);
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 3;
         e1 = tm.mark();
@@ -340,12 +340,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     const uint32_t *d_skip = &B.prep->skip;
     // ---- streaming first stage: two LSB passes + in-LDS bucket sorts; ends with the block's host round trip ----
     auto streaming = [&](int Q, const uint8_t *key_text) -> int {
-        memset(&h_ctl, 0, sizeof h_ctl);
-        h_ctl.min_depth = 5;
-        h_ctl.base_id = 0xFFFFFFFFu;
-        h_ctl.list_cap = kTieListCap;
-        memcpy(c->h_mail + 2048, &h_ctl, sizeof h_ctl);           // pinned staging: the upload does not block
-        ARCHON_HIP_TRY(hipMemcpyAsync(d_ctl, c->h_mail + 2048, sizeof h_ctl, hipMemcpyHostToDevice, s));
+        // (the tie summary was initialised on the device by k_rows_scan, which also left the count summary in it)
         iA0 = ps.mark();
         if (Q == 2)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 2>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, key_text, d_skip);
@@ -404,11 +399,10 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 6;
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_ctl, sizeof(bs::TieCtl), hipMemcpyDeviceToHost, s));
-        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 64, &B.prep->big_items, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         e3 = tm.mark();
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         memcpy(&h_ctl, c->h_mail, sizeof h_ctl);
-        big_items = c->h_mail[64];
+        big_items = h_ctl.big_items;
         return ARCHON_OK;
     };
     auto count_wait = [&]() -> int {             // routes that need the count on the host before going on
