@@ -338,6 +338,14 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     uint32_t big_items = 0;
     uint32_t *B_K = reinterpret_cast<uint32_t *>(B.keyB), *B_I = B_K + n + 8;
     const uint32_t *d_skip = &B.prep->skip;
+    // The byte histogram of the block comes with the two-byte count: its second-byte column sums are the bytes
+    // x[0..n-2] plus the 0xFF in front of x[0]; the host adds x[n-1] and removes the pad (alphabet detection below).
+    auto fetch_byte_counts = [&]() -> int {
+        c->h_mail[512] = 0;
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 128, B.prep->cntA, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 512, d_x + (n - 1), 1, hipMemcpyDeviceToHost, s));
+        return ARCHON_OK;
+    };
     // ---- streaming first stage: two LSB passes + in-LDS bucket sorts; ends with the block's host round trip ----
     auto streaming = [&](int Q, const uint8_t *key_text) -> int {
         // (the tie summary was initialised on the device by k_rows_scan, which also left the count summary in it)
@@ -400,6 +408,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         c->launches += 6;
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_ctl, sizeof(bs::TieCtl), hipMemcpyDeviceToHost, s));
         e3 = tm.mark();
+        if (Q == 1) ARCHON_TRY(fetch_byte_counts());              // free with the round trip; used only by skewed blocks
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         memcpy(&h_ctl, c->h_mail, sizeof h_ctl);
         big_items = h_ctl.big_items;
@@ -407,6 +416,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     };
     auto count_wait = [&]() -> int {             // routes that need the count on the host before going on
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 64, &B.prep->big_items, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_TRY(fetch_byte_counts());
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         big_items = c->h_mail[64];
         return ARCHON_OK;
@@ -429,13 +439,12 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         // heavily skewed at two bytes.  Alphabet compaction: with <= 16 distinct bytes a key
         // byte holds 2, 4 or 8 symbols; if the two-byte buckets of THAT text are small enough the block still
         // takes the streaming stage (DNA: 8 symbols deep after two passes), else the 7-pass sort on packed keys.
-        ARCHON_TRY(launch_hist256(s, d_x, n, d_counts, n));
-        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_counts, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
         uint8_t h_lut[256];
-        for (int v = 0; v < 256; ++v) {
+        const uint32_t last_byte = c->h_mail[512] & 0xFFu;
+        for (uint32_t v = 0; v < 256; ++v) {
+            const uint32_t cnt = c->h_mail[128 + v] - (v == 0xFFu ? 1u : 0u) + (v == last_byte ? 1u : 0u);
             h_lut[v] = (uint8_t)sigma;
-            if (c->h_mail[v]) ++sigma;
+            if (cnt) ++sigma;
         }
         bits = 1;
         while ((1u << bits) < sigma) ++bits;
@@ -444,7 +453,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             ARCHON_HIP_TRY(hipMemcpyAsync(d_lut, c->h_mail + 1024, 256, hipMemcpyHostToDevice, s));
             if (sigma >= 2 && geo == 2 && forced < 0 && !getenv("ARCHON_NO_PACK_STREAM")) {
                 const int q = bits == 1 ? 8 : bits == 2 ? 4 : 2;
-                const dim3 grid(div_up(div_up(n, 4), 256)), block(256);
+                const dim3 grid(div_up(div_up(n, 16), 256)), block(256);
                 if (q == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_build_y<8>), grid, block, 0, s, d_x, n, d_lut, B.y);
                 else if (q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_build_y<4>), grid, block, 0, s, d_x, n, d_lut, B.y);
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_build_y<2>), grid, block, 0, s, d_x, n, d_lut, B.y);
