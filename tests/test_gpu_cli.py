@@ -148,3 +148,33 @@ def test_bench_two_rank_rehearsal():
     assert line["n_gpus"] == 2 and line["config"]["blocks_per_step"] == 2
     assert line["config"]["sa_lf_consistent"] is True and line["config"]["gathered_block_round_trip"] is True
     assert line["value"] > 0 and "roofline" in line and "cpu_baseline" not in line
+
+
+def test_concurrent_host_threads(archon, oracle):
+    """calls on one device from several host threads are serialised by the per-device mutex
+    (ctypes releases the GIL during the call); every thread must get its own block's result."""
+    import threading
+    blocks = [S.gen_shape(sh, 200000 + 777 * i, block=i) for i, sh in enumerate(["random", "text", "dna", "ab", "random", "motif"])]
+    want = [oracle.forward(x) for x in blocks]
+    got = [None] * len(blocks)
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                sa, bwt, base = archon.forward(blocks[i])
+                back = archon.inverse(bwt, base)
+                assert (back == blocks[i]).all()
+            got[i] = (sa, bwt, base)
+        except Exception as e:      # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(blocks))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errs, errs
+    for i, (P, B, b0) in enumerate(want):
+        sa, bwt, base = got[i]
+        assert (sa == P).all() and (bwt == B).all() and base == b0, i
