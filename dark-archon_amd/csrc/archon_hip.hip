@@ -319,13 +319,14 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // bucket-per-workgroup pass B (Prep::aligned) needs 256 workgroups and enough tiles per bucket to matter
     const uint32_t allow_aligned = (geo == 2 && n >= (1u << 24) && !getenv("ARCHON_NO_ALIGNED")) ? 1u : 0u;
     int e1 = -1;
-    auto count16 = [&](int Q, const uint8_t *src, bool force_stream) -> int {
-        ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, (size_t)(reinterpret_cast<char *>(&B.prep->cntA[256]) - reinterpret_cast<char *>(B.hist16)), s));
+    auto count16 = [&](int Q, const uint8_t *src, bool force_stream, bool probe = false) -> int {
+        uint32_t *d_suspect = probe ? &B.prep->suspect : nullptr;
+        ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, (size_t)(reinterpret_cast<char *>(&B.prep->rowtot[0]) - reinterpret_cast<char *>(B.hist16)), s));
         const dim3 grid(R, 2), block(bs::kH16Block);
-        if (Q == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<1>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
-        else if (Q == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<2>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
-        else if (Q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<4>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist);
+        if (Q == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<1>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect);
+        else if (Q == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<2>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect);
+        else if (Q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<4>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect);
         hipLaunchKernelGGL(bs::k_rows_total, dim3(256), dim3(256), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
         hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep, force_stream ? 1u : 0u, allow_aligned, d_ctl, (uint32_t)kTieListCap);
         ARCHON_HIP_TRY(hipGetLastError());
@@ -428,7 +429,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     if (const char *f = getenv("ARCHON_FORCE_PATH")) forced = atoi(f) ? 1 : 0;
     int path;
     int Q = 1;                                   // symbols per key byte on the streaming path
-    ARCHON_TRY(count16(1, d_x, forced == 1));
+    const bool probe = forced < 0 && !getenv("ARCHON_NO_PROBE");
+    ARCHON_TRY(count16(1, d_x, forced == 1, probe));
     if (forced == 0) {
         ARCHON_TRY(count_wait());
         path = 0;
@@ -438,16 +440,40 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     }
     uint32_t sigma = 0, bits = 8;
     uint8_t *d_lut = reinterpret_cast<uint8_t *>(small + 900);
+    uint8_t h_lut[256];
+    bool have_lut = false;
+    if (probe && h_ctl.suspect) {
+        // a workgroup of the count saw at most 4 distinct bytes and the count was abandoned (k_hist16): get the exact
+        // alphabet from a presence map; a block that only LOOKED poor is counted again without the probe
+        hipLaunchKernelGGL(bs::k_presence, dim3(kNumCU * 8), dim3(256), 0, s, d_x, n, B.prep->present);
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 520, B.prep->present, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        ++c->launches;
+        for (uint32_t v = 0; v < 256; ++v) {
+            h_lut[v] = (uint8_t)sigma;
+            if ((c->h_mail[520 + (v >> 5)] >> (v & 31u)) & 1u) ++sigma;
+        }
+        if (sigma <= 16 && !getenv("ARCHON_NO_PACK")) {
+            have_lut = true;
+            path = 0;
+        } else {
+            sigma = 0;
+            ARCHON_TRY(count16(1, d_x, false, false));
+            ARCHON_TRY(streaming(1, d_x));
+            path = ((uint64_t)big_items * 2 <= n) ? 1 : 0;
+        }
+    }
     if (path == 0) {
         // heavily skewed at two bytes.  Alphabet compaction: with <= 16 distinct bytes a key
         // byte holds 2, 4 or 8 symbols; if the two-byte buckets of THAT text are small enough the block still
         // takes the streaming stage (DNA: 8 symbols deep after two passes), else the 7-pass sort on packed keys.
-        uint8_t h_lut[256];
-        const uint32_t last_byte = c->h_mail[512] & 0xFFu;
-        for (uint32_t v = 0; v < 256; ++v) {
-            const uint32_t cnt = c->h_mail[128 + v] - (v == 0xFFu ? 1u : 0u) + (v == last_byte ? 1u : 0u);
-            h_lut[v] = (uint8_t)sigma;
-            if (cnt) ++sigma;
+        if (!have_lut) {
+            const uint32_t last_byte = c->h_mail[512] & 0xFFu;
+            for (uint32_t v = 0; v < 256; ++v) {
+                const uint32_t cnt = c->h_mail[128 + v] - (v == 0xFFu ? 1u : 0u) + (v == last_byte ? 1u : 0u);
+                h_lut[v] = (uint8_t)sigma;
+                if (cnt) ++sigma;
+            }
         }
         bits = 1;
         while ((1u << bits) < sigma) ++bits;

@@ -255,8 +255,9 @@ def test_compacted_alphabet_streaming(archon, oracle, sigma, n):
     P, B, b0 = oracle.forward(x)
     assert (sa == P).all()
     assert (bwt == B).all() and base == b0
-    # two-byte buckets small enough already (n / sigma^2 under the 4608-item cap): plain bytes, no recode
-    want_bits = 0 if n / sigma**2 < 4400 else (1 if sigma == 2 else 2 if sigma <= 4 else 4)
+    # at most 4 distinct bytes: the count's probe sends the block to the recode at once; otherwise two-byte buckets
+    # that are small enough already (n / sigma^2 under the 4608-item cap) keep plain bytes
+    want_bits = (1 if sigma == 2 else 2) if sigma <= 4 else (0 if n / sigma**2 < 4400 else 4)
     assert st["path"] == 1 and st["alphabet_bits"] == want_bits
 
 
