@@ -46,3 +46,49 @@ def test_fuzz_both_paths(archon, oracle, seed):
             assert (sa == P).all() and (bwt == B).all() and base == b0, (path, x.size, x[:16])
         assert (archon.inverse(B, b0) == x).all()
         assert archon.validate(x, P)
+
+
+def _natural_cases(rng, count):
+    """bigger blocks, structures that steer the un-forced route: probe / recode, skip flag, run shortcut, doubling"""
+    for _ in range(count):
+        n = int(rng.choice([3000, 70000, 300000, 1 << 20, (1 << 21) + 5]))
+        n += int(rng.integers(-50, 51))
+        kind = int(rng.integers(0, 7))
+        if kind == 0:        # uniform bytes
+            x = rng.integers(0, 256, size=n, dtype=np.uint8)
+        elif kind == 1:      # small alphabet, maybe with a rare extra symbol (defeats the 4-symbol probe late in the block)
+            k = int(rng.choice([2, 3, 4, 5, 12, 16, 17, 40]))
+            x = rng.choice(np.sort(rng.choice(256, size=k, replace=False)).astype(np.uint8), size=n)
+            if rng.integers(0, 2):
+                x[int(rng.integers(n // 2, n))] = np.uint8(rng.integers(0, 256))
+        elif kind == 2:      # a motif repeated, with a few point defects
+            m = int(rng.choice([1, 2, 3, 7, 100, 1000, 4099]))
+            x = np.tile(rng.integers(0, 256, size=m, dtype=np.uint8), n // m + 1)[:n].copy()
+            for _ in range(int(rng.integers(0, 4))):
+                x[int(rng.integers(0, n))] ^= np.uint8(1 + rng.integers(0, 255))
+        elif kind == 3:      # random text with a long duplicated chunk (deep ties next to shallow ones)
+            x = rng.integers(97, 123, size=n, dtype=np.uint8)
+            L = int(rng.integers(10, max(11, n // 3)))
+            a, b = int(rng.integers(0, n - L)), int(rng.integers(0, n - L))
+            x[b:b + L] = x[a:a + L].copy()
+        elif kind == 4:      # runs of random length
+            vals = rng.integers(0, 256, size=n // 20 + 2, dtype=np.uint8)
+            x = np.repeat(vals, rng.integers(1, 40, size=vals.size))[:n]
+            if x.size < n:
+                x = np.concatenate([x, rng.integers(0, 256, size=n - x.size, dtype=np.uint8)])
+        elif kind == 5:      # two halves of different character
+            h = n // 2
+            x = np.concatenate([rng.choice(np.frombuffer(b"ACGT", np.uint8), size=h), rng.integers(0, 256, size=n - h, dtype=np.uint8)])
+        else:                # 0xFF-heavy with structure
+            x = np.where(rng.random(n) < 0.9, 255, rng.integers(250, 256, size=n)).astype(np.uint8)
+        yield np.ascontiguousarray(x, np.uint8)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_fuzz_natural_route(archon, oracle, seed):
+    rng = np.random.default_rng(seed)
+    for x in _natural_cases(rng, 12):
+        P, B, b0 = oracle.forward(x)
+        sa, bwt, base = archon.forward(x)
+        assert (sa == P).all() and (bwt == B).all() and base == b0, (x.size, x[:16], archon.stats())
+        assert (archon.inverse(B, b0) == x).all()
