@@ -136,7 +136,7 @@ def main():
     sa_t = None if args.no_sa else torch.empty(n, dtype=torch.int32, device=dev)
     # BWT || baseId (LE), double-buffered: the gather of step k runs on RCCL's stream while step k+1 sorts
     outs = [torch.empty(n + 4, dtype=torch.uint8, device=dev) for _ in range(2)]
-    base_t = torch.zeros(1, dtype=torch.int32, device=dev)
+    base_views = [o[n:].view(torch.int32) for o in outs]       # n is a multiple of 4: aligned
     gather_lists = [None, None]
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
     if dist is not None and rank == 0:
@@ -154,8 +154,7 @@ def main():
             pending[k].wait()
             pending[k] = None
         out_t = outs[k]
-        pyarchon.forward_dev(x_t, sa_t, out_t[:n], base_t)
-        out_t[n:] = base_t.view(torch.uint8)
+        pyarchon.forward_dev(x_t, sa_t, out_t[:n], base_views[k])      # baseId lands behind the BWT: BWT || baseId (LE)
         st = pyarchon.stats(local_rank)
         pass_ms.append(st["ms_radix_pass_sum"])
         pass_cnt.append(st["radix_pass_timed"])
