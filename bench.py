@@ -110,6 +110,12 @@ def main():
 
     pyarchon.lib()   # fail loudly if the HIP extension is missing
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        # RCCL's send/recv kernels hold CUs while the gather of step k overlaps the sort of step k+1, and a pass
+        # workgroup needs a whole CU (all its registers): with one range per CU a few lost CUs mean a second round,
+        # i.e. a pass twice as long.  1024 ranges keep that tail at a quarter of a round.
+        os.environ.setdefault("ARCHON_PASS_RANGES", "1024")
+        os.environ.setdefault("ARCHON_NO_ALIGNED", "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -244,6 +250,7 @@ def main():
                 "sa_emitted": sa_t is not None,
                 "sa_lf_consistent": ok,
                 "gathered_block_round_trip": gathered_ok,
+                "pass_ranges": int(os.environ.get("ARCHON_PASS_RANGES", "256")),
             },
             "roofline": {
                 "bound": "hbm",

@@ -329,8 +329,9 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect);
         hipLaunchKernelGGL(bs::k_rows_total, dim3(256), dim3(256), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
         hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep, force_stream ? 1u : 0u, allow_aligned, d_ctl, (uint32_t)kTieListCap);
+        hipLaunchKernelGGL(bs::k_col_prefix, dim3(256), dim3(1024), 0, s, rhist, R, &B.prep->skip);
         ARCHON_HIP_TRY(hipGetLastError());
-        c->launches += 3;
+        c->launches += 4;
         e1 = tm.mark();
         return ARCHON_OK;
     };
@@ -377,6 +378,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         RB = div_up(ntilesB, tprB);
         const uint32_t gridB = allow_aligned ? 256u : RB;      // surplus workgroups of the range mode return at once
         hipLaunchKernelGGL(bs::k_range_hist_text, dim3(RB), dim3(bs::kRhBlock), 0, s, A_B1, n, tprB, rhist, 0u, tileB, d_skip);
+        hipLaunchKernelGGL(bs::k_col_prefix, dim3(256), dim3(1024), 0, s, rhist, RB, d_skip);          // (harmless in bucket mode: the table is not read)
         iB0 = ps.mark();
         unsigned long long *d_stamps = reinterpret_cast<unsigned long long *>(small + 800);
         if (dbg & 4u)
@@ -409,7 +411,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         hipLaunchKernelGGL(bs::k_resolve_ties, dim3(div_up(kTieListCap, 256)), dim3(256), 0, s, d_x, n, B.tie_list, d_ctl,
                            sa, d_bwt, 5u * (uint32_t)Q, 64u * (uint32_t)Q, d_skip);
         ARCHON_HIP_TRY(hipGetLastError());
-        c->launches += 6;
+        c->launches += 7;
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_ctl, sizeof(bs::TieCtl), hipMemcpyDeviceToHost, s));
         e3 = tm.mark();
         if (Q == 1) ARCHON_TRY(fetch_byte_counts());              // free with the round trip; used only by skewed blocks
