@@ -373,10 +373,12 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         // pass B has its own tiling of the pass-A output
         const uint32_t ntilesB = div_up(n, tileB);
         uint32_t RB = (uint32_t)kNumCU * wg_per_cu;
+        if (const char *e = getenv("ARCHON_PASS_RANGES")) RB = (uint32_t)atoi(e);
+        if (RB > (uint32_t)bs::kMaxRanges) RB = bs::kMaxRanges;
         if (RB > ntilesB) RB = ntilesB;
         const uint32_t tprB = div_up(ntilesB, RB);
         RB = div_up(ntilesB, tprB);
-        const uint32_t gridB = allow_aligned ? 256u : RB;      // surplus workgroups of the range mode return at once
+        const uint32_t gridB = (allow_aligned && RB < 256u) ? 256u : RB;      // bucket mode needs 256; surplus workgroups return at once
         hipLaunchKernelGGL(bs::k_range_hist_text, dim3(RB), dim3(bs::kRhBlock), 0, s, A_B1, n, tprB, rhist, 0u, tileB, d_skip);
         hipLaunchKernelGGL(bs::k_col_prefix, dim3(256), dim3(1024), 0, s, rhist, RB, d_skip);          // (harmless in bucket mode: the table is not read)
         iB0 = ps.mark();
