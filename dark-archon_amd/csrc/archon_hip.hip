@@ -322,11 +322,14 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     auto count16 = [&](int Q, const uint8_t *src, bool force_stream, bool probe = false) -> int {
         uint32_t *d_suspect = probe ? &B.prep->suspect : nullptr;
         ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, (size_t)(reinterpret_cast<char *>(&B.prep->rowtot[0]) - reinterpret_cast<char *>(B.hist16)), s));
-        const dim3 grid(R, 2), block(bs::kH16Block);
-        if (Q == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<1>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect);
-        else if (Q == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<2>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect);
-        else if (Q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<4>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect);
+        // the count runs with at most 256 workgroups per half: with more pass ranges each workgroup covers several of
+        // them and reads the column sums off between two (more workgroups would only flush their 32 768 bins more often)
+        const uint32_t sub = (R > 256u && R % 256u == 0u) ? R / 256u : 1u;
+        const dim3 grid(R / sub, 2), block(bs::kH16Block);
+        if (Q == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<1>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect, sub);
+        else if (Q == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<2>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect, sub);
+        else if (Q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<4>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect, sub);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect, sub);
         hipLaunchKernelGGL(bs::k_rows_total, dim3(256), dim3(256), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
         hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep, force_stream ? 1u : 0u, allow_aligned, d_ctl, (uint32_t)kTieListCap);
         hipLaunchKernelGGL(bs::k_col_prefix, dim3(256), dim3(1024), 0, s, rhist, R, &B.prep->skip);
