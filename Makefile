@@ -39,3 +39,12 @@ clean:
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib host cli oracle clean
+
+# micro-benchmarks and test-only kernels behind the measurements quoted in DESIGN.md (not part of the product)
+micro: tools/micro/scatter_bw tools/micro/scatter_align tools/micro/libcu_hog.so
+tools/micro/scatter_bw: tools/micro/scatter_bw.hip
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -o $@ $<
+tools/micro/scatter_align: tools/micro/scatter_align.hip
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -o $@ $<
+tools/micro/libcu_hog.so: tools/micro/cu_hog.hip
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -fPIC -shared -o $@ $<
