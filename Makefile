@@ -38,7 +38,7 @@ clean:
 	rm -rf bin $(LIB) $(PKG)/libarchon.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib host cli oracle clean
+.PHONY: all lib host cli oracle clean micro
 
 # micro-benchmarks and test-only kernels behind the measurements quoted in DESIGN.md (not part of the product)
 micro: tools/micro/scatter_bw tools/micro/scatter_align tools/micro/libcu_hog.so
