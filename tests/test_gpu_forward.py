@@ -354,3 +354,17 @@ def test_mid_sizes_lf_consistent(archon, shape, n):
     out_t = torch.empty(n, dtype=torch.uint8, device="cuda")
     archon.inverse_dev(bwt_t, int(base_t.item()), out_t)
     assert torch.equal(out_t, x_t)
+
+
+@pytest.mark.parametrize("ranges", ["1024", "512", "300", "7"])
+def test_many_pass_ranges(archon, oracle, monkeypatch, ranges):
+    """bench.py cuts the passes into 1024 ranges for N > 1 (shorter tails when RCCL holds CUs): prefix-summed range
+    tables (k_col_prefix), the two-byte count covering several pass ranges per workgroup, pass B in range mode."""
+    monkeypatch.setenv("ARCHON_PASS_RANGES", ranges)
+    monkeypatch.setenv("ARCHON_NO_ALIGNED", "1")
+    for shape, n in (("random", (1 << 24) + 4321), ("random", 3000001), ("dna", (1 << 23) + 99), ("random", 70000)):
+        x = S.gen_shape(shape, n)
+        P = oracle.sa(x)
+        sa, bwt, base = archon.forward(x)
+        assert archon.stats()["path"] == 1
+        assert (sa == P).all(), (shape, n)
