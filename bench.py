@@ -4,9 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic input: every
-rank runs the whole forward pipeline (hist256 -> LSB radix bucketing -> prefix
-doubling -> sa_to_bwt, SA emitted) on its own 256 MiB block of uniform random
-bytes already resident in HBM (BASELINE.json configs[1], SURVEY.md 8(d) cfg 2;
+rank runs the whole forward pipeline (two-byte count -> two LSB radix passes ->
+in-LDS bucket sorts -> tie resolution; prefix doubling where ties remain; SA and
+BWT emitted) on its own 256 MiB block of uniform random bytes already resident
+in HBM (BASELINE.json configs[1], SURVEY.md 8(d) cfg 2;
 block b is seeded SEED_BASE+2+b), and for N>1 the per-block outputs BWT||baseId
 are gathered to rank 0 over RCCL (the path's one exchange step).
 The gather of step k is asynchronous (RCCL's own stream) and overlaps the sort of step k+1; the
