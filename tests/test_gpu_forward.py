@@ -368,3 +368,8 @@ def test_many_pass_ranges(archon, oracle, monkeypatch, ranges):
         sa, bwt, base = archon.forward(x)
         assert archon.stats()["path"] == 1
         assert (sa == P).all(), (shape, n)
+    # a size whose tile count is a multiple of 256: the two-byte count then covers several pass ranges per workgroup
+    x = S.gen_random(1 << 25)
+    sa, bwt, base = archon.forward(x)
+    assert archon.stats()["path"] == 1 and archon.validate(x, sa)
+    assert (archon.inverse(bwt, base) == x).all()
