@@ -15,7 +15,7 @@ for ranges, aligned in (("256", None), ("1024", "1")):
     os.environ["ARCHON_PASS_RANGES"] = ranges
     if aligned: os.environ["ARCHON_NO_ALIGNED"] = aligned
     else: os.environ.pop("ARCHON_NO_ALIGNED", None)
-    for k in (0, 8, 16, 32):
+    for k in (0, 1, 2, 8, 32):
         best = 1e9
         for rep in range(3):
             torch.cuda.synchronize()
