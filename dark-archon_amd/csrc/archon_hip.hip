@@ -106,6 +106,7 @@ static size_t forward_arena_bytes(uint32_t n)
     add(4 * (size_t)bs::kMaxRanges * 256);    // range table of the passes
     add(sizeof(bs::Prep));
     add(sizeof(uint2) * kTieListCap);
+    add(sizeof(uint4) * (size_t)bs::kMaxRanges * bs::kTrashWords);
     add(4 * 1024);                            // counts, starts, ticket, err, base, totals, TieCtl
     return b + 4096;
 }
@@ -119,6 +120,7 @@ struct FwdBuf {
     uint32_t *scan_tmp, *hist16, *small;
     bs::Prep *prep;
     uint2 *tie_list;
+    uint4 *trash;              // write-only trash lines of the pass workgroups (passes.hiph, emit_rec)
     rs::Scratch sc;
 };
 
@@ -266,6 +268,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     B.rhist = c->alloc<uint32_t>((size_t)bs::kMaxRanges * 256);  // } (hist16, range table, the counters that
     B.prep = c->alloc<bs::Prep>(1);                             // }  open Prep)
     B.tie_list = c->alloc<uint2>(kTieListCap);
+    B.trash = c->alloc<uint4>((size_t)bs::kMaxRanges * bs::kTrashWords);
     B.small = c->alloc<uint32_t>(1024);
     if (!B.small) {
         set_error("arena exhausted");
@@ -295,29 +298,36 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // A2 / bucket setup: the two-byte count (a4 compute(), archon.c:146-161) and its scans.  The count
     // runs over the tile ranges of LSB pass A (R contiguous ranges, one persistent workgroup each), so
     // the same sweep also delivers that pass's per-range digit table.
-    // pass geometries: 0: 512x16 = tiles of 8192, 2 workgroups/CU; 1: 1024x8, 1/CU; 2: 1024x16 = tiles of 16384, 1/CU; 3: 512x32 = tiles of 16384, 1/CU, 256 VGPRs
-    const int geo = getenv("ARCHON_PASS_GEOMETRY") ? atoi(getenv("ARCHON_PASS_GEOMETRY")) : 2;   // compacted alphabets: 2 only
-    const uint32_t tileA = geo >= 2 ? 16384u : 8192u, tileB = tileA;
-    const uint32_t wg_per_cu = geo == 0 ? 2u : 1u;
-    const uint32_t ntiles = div_up(n, tileA);
-    uint32_t R = (uint32_t)kNumCU * wg_per_cu;            // = co-resident workgroups
-    if (const char *e = getenv("ARCHON_PASS_RANGES")) R = (uint32_t)atoi(e);
-    if (R > (uint32_t)bs::kMaxRanges) R = bs::kMaxRanges;
+    // Pass geometry: 1024 lanes x 12 items = tiles of 12 288 items, one workgroup per CU (passes.hiph).
+    constexpr uint32_t kTileItems = bs::kPassTile;
+    const uint32_t ntiles = div_up(n, kTileItems);
+    // ARCHON_PASS_RANGES: ranges the passes are cut into (default: one per CU).  bench.py asks for 1024 at N > 1
+    // (shorter tails while RCCL's kernels hold CUs); tests use odd counts.  Whatever is asked for, a range never
+    // exceeds 2^24 items (pass A stages positions relative to its range start in 24 bits).
+    uint32_t R = (uint32_t)kNumCU;
+    if (const char *e = getenv("ARCHON_PASS_RANGES")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v < 1 || v > bs::kMaxRanges) { set_error("ARCHON_PASS_RANGES=%s out of range [1, %d]", e, bs::kMaxRanges); return ARCHON_E_ARG; }
+        R = (uint32_t)v;
+    }
     if (R > ntiles) R = ntiles;
-    const uint32_t tpr = div_up(ntiles, R);
+    uint32_t tpr = div_up(ntiles, R);
+    const uint32_t tpr_max = bs::kRangeMaxItems / kTileItems;
+    if (tpr > tpr_max) tpr = tpr_max;
     R = div_up(ntiles, tpr);
+    if (R > (uint32_t)bs::kMaxRanges) { set_error("block of %u bytes needs %u pass ranges (max %d)", n, R, bs::kMaxRanges); return ARCHON_E_INTERNAL; }
     uint32_t *rhist = B.rhist;                  // [R][256], reused by both passes
     // Q = symbols per key byte of the streaming stage: 1 = plain bytes; 2/4/8 = compacted alphabet (below)
     StageTimer ps(c, 48, s);                            // streaming stage: pass A, pass B (their own HIP events)
     int iA0 = -1, iA1 = -1, iB0 = -1, iB1 = -1;
-    uint32_t *A_K = reinterpret_cast<uint32_t *>(B.keyA), *A_I = A_K + n + 8;
+    uint2 *A_R = reinterpret_cast<uint2 *>(B.keyA);     // pass A out: {K, I} records + the first-key-byte stream
     uint8_t *A_B1 = reinterpret_cast<uint8_t *>(B.valA);
-    const uint32_t dbg = getenv("ARCHON_DEBUG") ? (uint32_t)atoi(getenv("ARCHON_DEBUG")) : 0u;   // timing experiments only
+    uint2 *B_R = reinterpret_cast<uint2 *>(B.keyB);     // pass B out
     // The two-byte count decides the route.  The host does not wait for it: the count leaves a `skip` flag on the
     // device, the whole streaming stage is queued behind it, and its kernels return at once when the flag says
     // "skewed".  One host round trip per block (after k_resolve_ties) instead of two.
     // bucket-per-workgroup pass B (Prep::aligned) needs 256 workgroups and enough tiles per bucket to matter
-    const uint32_t allow_aligned = (geo == 2 && n >= (1u << 24) && !getenv("ARCHON_NO_ALIGNED")) ? 1u : 0u;
+    const uint32_t allow_aligned = (n >= (1u << 24) && !getenv("ARCHON_NO_ALIGNED")) ? 1u : 0u;
     int e1 = -1;
     auto count16 = [&](int Q, const uint8_t *src, bool force_stream, bool probe = false) -> int {
         uint32_t *d_suspect = probe ? &B.prep->suspect : nullptr;
@@ -326,10 +336,10 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         // them and reads the column sums off between two (more workgroups would only flush their 32 768 bins more often)
         const uint32_t sub = (R > 256u && R % 256u == 0u) ? R / 256u : 1u;
         const dim3 grid(R / sub, 2), block(bs::kH16Block);
-        if (Q == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<1>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect, sub);
-        else if (Q == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<2>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect, sub);
-        else if (Q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<4>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect, sub);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.hist16, tpr * tileA, rhist, d_suspect, sub);
+        if (Q == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<1>), grid, block, 0, s, src, n, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
+        else if (Q == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<2>), grid, block, 0, s, src, n, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
+        else if (Q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<4>), grid, block, 0, s, src, n, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
         hipLaunchKernelGGL(bs::k_rows_total, dim3(256), dim3(256), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
         hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep, force_stream ? 1u : 0u, allow_aligned, d_ctl, (uint32_t)kTieListCap);
         hipLaunchKernelGGL(bs::k_col_prefix, dim3(256), dim3(1024), 0, s, rhist, R, &B.prep->skip);
@@ -340,8 +350,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     };
     int e2 = -1, e2b = -1, e3 = -1, e4 = -1;
     bs::TieCtl h_ctl;
+    memset(&h_ctl, 0, sizeof h_ctl);
     uint32_t big_items = 0;
-    uint32_t *B_K = reinterpret_cast<uint32_t *>(B.keyB), *B_I = B_K + n + 8;
     const uint32_t *d_skip = &B.prep->skip;
     // The byte histogram of the block comes with the two-byte count: its second-byte column sums are the bytes
     // x[0..n-2] plus the 0xFF in front of x[0]; the host adds x[n-1] and removes the pad (alphabet detection below).
@@ -354,65 +364,29 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // ---- streaming first stage: two LSB passes + in-LDS bucket sorts; ends with the block's host round trip ----
     auto streaming = [&](int Q, const uint8_t *key_text) -> int {
         // (the tie summary was initialised on the device by k_rows_scan, which also left the count summary in it)
+        constexpr int PB = bs::kPassBlock, PI = bs::kPassIPT;
         iA0 = ps.mark();
         if (Q == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 2>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, key_text, d_skip);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 2>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, key_text, d_skip, B.trash);
         else if (Q == 4)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, key_text, d_skip);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 4>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, key_text, d_skip, B.trash);
         else if (Q == 8)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 8>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, key_text, d_skip);
-        else if (dbg & 16u)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4, 1, true>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, 0u, d_x, d_skip,
-                               reinterpret_cast<unsigned long long *>(small + 840));
-        else if (geo == 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 8, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x, d_skip);
-        else if (geo == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<1024, 16, 4>), dim3(R), dim3(1024), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x, d_skip);
-        else if (geo == 3)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 32, 2>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x, d_skip);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 8>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, key_text, d_skip, B.trash);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<512, 16, 4>), dim3(R), dim3(512), 0, s, d_x, n, tpr, A_K, A_I, A_B1, B.prep->startA, rhist, dbg, d_x, d_skip);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 1>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, d_x, d_skip, B.trash);
         iA1 = ps.mark();
-        // pass B has its own tiling of the pass-A output
-        const uint32_t ntilesB = div_up(n, tileB);
-        uint32_t RB = (uint32_t)kNumCU * wg_per_cu;
-        if (const char *e = getenv("ARCHON_PASS_RANGES")) RB = (uint32_t)atoi(e);
-        if (RB > (uint32_t)bs::kMaxRanges) RB = bs::kMaxRanges;
-        if (RB > ntilesB) RB = ntilesB;
-        const uint32_t tprB = div_up(ntilesB, RB);
-        RB = div_up(ntilesB, tprB);
-        const uint32_t gridB = (allow_aligned && RB < 256u) ? 256u : RB;      // bucket mode needs 256; surplus workgroups return at once
-        hipLaunchKernelGGL(bs::k_range_hist_text, dim3(RB), dim3(bs::kRhBlock), 0, s, A_B1, n, tprB, rhist, 0u, tileB, d_skip);
-        hipLaunchKernelGGL(bs::k_col_prefix, dim3(256), dim3(1024), 0, s, rhist, RB, d_skip);          // (harmless in bucket mode: the table is not read)
+        // pass B walks the same tile grid in the same ranges; in bucket mode (Prep::aligned) workgroup c takes bucket c
+        const uint32_t gridB = (allow_aligned && R < 256u) ? 256u : R;      // bucket mode needs 256; surplus workgroups return at once
+        hipLaunchKernelGGL(bs::k_range_hist_text, dim3(R), dim3(bs::kRhBlock), 0, s, A_B1, n, tpr, rhist, 0u, kTileItems, d_skip);
+        hipLaunchKernelGGL(bs::k_col_prefix, dim3(256), dim3(1024), 0, s, rhist, R, d_skip);          // (harmless in bucket mode: the table is not read)
         iB0 = ps.mark();
-        unsigned long long *d_stamps = reinterpret_cast<unsigned long long *>(small + 800);
-        if (dbg & 4u)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 16, 4, true>), dim3(gridB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg & 1u, d_stamps, B.prep->startA, d_skip, B.prep->start16);
-        else if (geo == 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 8, 4, false>), dim3(gridB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip, B.prep->start16);
-        else if (geo == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<1024, 16, 4, false>), dim3(gridB), dim3(1024), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip, B.prep->start16);
-        else if (geo == 3)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 32, 2, false>), dim3(gridB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip, B.prep->start16);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<512, 16, 4, false>), dim3(gridB), dim3(512), 0, s, A_K, A_I, A_B1, n, tprB, B_K, B_I,
-                               B.prep->startB, rhist, dbg, d_stamps, B.prep->startA, d_skip, B.prep->start16);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<PB, PI>), dim3(gridB), dim3(PB), 0, s, A_R, A_B1, n, tpr, B_R,
+                           B.prep->startB, rhist, B.prep->startA, d_skip, B.prep->start16, B.trash);
         iB1 = ps.mark();
         e2 = tm.mark();
-        if (dbg & 32u) {
-            // line-alignment timing experiment: the passes wrote garbage, nothing downstream may look at it
-        } else if (dbg & 8u)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_local_sort<true>), dim3(65536), dim3(bs::kLsBlock), 0, s, B_K, B_I, B.prep->start16, n, sa,
-                               d_bwt, d_ctl, B.tie_list, reinterpret_cast<unsigned long long *>(small + 820), d_skip);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_local_sort<false>), dim3(65536), dim3(bs::kLsBlock), 0, s, B_K, B_I, B.prep->start16, n, sa,
-                               d_bwt, d_ctl, B.tie_list, reinterpret_cast<unsigned long long *>(small + 820), d_skip);
+        hipLaunchKernelGGL(bs::k_local_sort, dim3(65536), dim3(bs::kLsBlock), 0, s, B_R, B.prep->start16, n, sa,
+                           d_bwt, d_ctl, B.tie_list, d_skip);
         e2b = tm.mark();
-        if (!(dbg & 32u))
         hipLaunchKernelGGL(bs::k_resolve_ties, dim3(div_up(kTieListCap, 256)), dim3(256), 0, s, d_x, n, B.tie_list, d_ctl,
                            sa, d_bwt, 5u * (uint32_t)Q, 64u * (uint32_t)Q, d_skip);
         ARCHON_HIP_TRY(hipGetLastError());
@@ -423,6 +397,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         memcpy(&h_ctl, c->h_mail, sizeof h_ctl);
         big_items = h_ctl.big_items;
+        if (h_ctl.fault) { set_error("tie list names rows outside the block (device flag 0x%x)", h_ctl.fault); return ARCHON_E_INTERNAL; }
         return ARCHON_OK;
     };
     auto count_wait = [&]() -> int {             // routes that need the count on the host before going on
@@ -432,7 +407,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         big_items = c->h_mail[64];
         return ARCHON_OK;
     };
-    int forced = -1;
+    int forced = -1;                             // ARCHON_FORCE_PATH (tests): 0 = 7-pass route, 1 = streaming stage
     if (const char *f = getenv("ARCHON_FORCE_PATH")) forced = atoi(f) ? 1 : 0;
     int path;
     int Q = 1;                                   // symbols per key byte on the streaming path
@@ -487,7 +462,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         if (sigma <= 16 && !getenv("ARCHON_NO_PACK")) {
             memcpy(c->h_mail + 1024, h_lut, 256);
             ARCHON_HIP_TRY(hipMemcpyAsync(d_lut, c->h_mail + 1024, 256, hipMemcpyHostToDevice, s));
-            if (sigma >= 2 && geo == 2 && forced < 0 && !getenv("ARCHON_NO_PACK_STREAM")) {
+            if (sigma >= 2 && forced < 0 && !getenv("ARCHON_NO_PACK_STREAM")) {
                 const int q = bits == 1 ? 8 : bits == 2 ? 4 : 2;
                 const dim3 grid(div_up(div_up(n, 16), 256)), block(256);
                 if (q == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_build_y<8>), grid, block, 0, s, d_x, n, d_lut, B.y);
@@ -518,27 +493,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         st.tie_items = h_ctl.tie_items;
         st.ms_local_sort = tm.ms(e2, e2b);
         st.ms_resolve = tm.ms(e2b, e3);
-        if (dbg & 16u) {
-            unsigned long long hs[8];
-            ARCHON_HIP_TRY(hipMemcpy(hs, small + 840, sizeof hs, hipMemcpyDeviceToHost));
-            fprintf(stderr, "pass A stamps (cycles, workgroup 0): load+keys %llu | rank %llu | rank-barrier %llu | layout %llu | emitK %llu | emitIB %llu | advance %llu\n",
-                    hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6]);
-        }
-        if (dbg & 4u) {
-            unsigned long long hs[8];
-            ARCHON_HIP_TRY(hipMemcpy(hs, small + 800, sizeof hs, hipMemcpyDeviceToHost));
-            fprintf(stderr, "pass B stamps (cycles, workgroup 0): load-issue %llu | load-wait %llu | rank %llu | layout %llu | emitK %llu | emitI %llu | rank-barrier %llu | advance %llu\n",
-                    hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7]);
-        }
-        if (dbg & 8u) {
-            unsigned long long hs[8];
-            ARCHON_HIP_TRY(hipMemcpy(hs, small + 820, sizeof hs, hipMemcpyDeviceToHost));
-            fprintf(stderr, "local sort stamps (cycles, bucket 30000): loads %llu | barrier %llu | atomics %llu | scan %llu | scatterK %llu | rank-loops %llu | write-IC %llu | output %llu\n",
-                    hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7]);
-        }
-        if (dbg & 33u) {
-            need_general = false;   // timing experiment: outputs are garbage
-        } else if (h_ctl.unresolved == 0 && h_ctl.tie_groups <= kTieListCap) {
+        if (h_ctl.unresolved == 0 && h_ctl.tie_groups <= kTieListCap) {
             need_general = false;
             if (h_ctl.base_id >= n) { set_error("primary index not found"); return ARCHON_E_INTERNAL; }
             ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, &d_ctl->base_id, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
