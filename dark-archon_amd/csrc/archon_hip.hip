@@ -380,7 +380,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         hipLaunchKernelGGL(bs::k_range_hist_text, dim3(R), dim3(bs::kRhBlock), 0, s, A_B1, n, tpr, rhist, 0u, kTileItems, d_skip);
         hipLaunchKernelGGL(bs::k_col_prefix, dim3(256), dim3(1024), 0, s, rhist, R, d_skip);          // (harmless in bucket mode: the table is not read)
         iB0 = ps.mark();
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<PB, PI>), dim3(gridB), dim3(PB), 0, s, A_R, A_B1, n, tpr, B_R,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<bs::kPassBBlock, bs::kPassBIPT>), dim3(gridB), dim3(bs::kPassBBlock), 0, s, A_R, A_B1, n, tpr, B_R,
                            B.prep->startB, rhist, B.prep->startA, d_skip, B.prep->start16, B.trash);
         iB1 = ps.mark();
         e2 = tm.mark();
