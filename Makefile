@@ -48,3 +48,8 @@ tools/micro/scatter_align: tools/micro/scatter_align.hip
 	$(HIPCC) -O3 --offload-arch=$(ARCH) -o $@ $<
 tools/micro/libcu_hog.so: tools/micro/cu_hog.hip
 	$(HIPCC) -O3 --offload-arch=$(ARCH) -fPIC -shared -o $@ $<
+
+# experiments build for tools/ (phase stamps etc.); never loaded by the product, the tests or bench.py
+exp: $(PKG)/libarchon_hip_exp.so
+$(PKG)/libarchon_hip_exp.so: $(CSRC)/archon_hip.hip $(wildcard $(CSRC)/*.hiph) include/archon_hip.h
+	$(HIPCC) $(HIPFLAGS) -DARCHON_EXPERIMENTS $(EXPFLAGS) -shared -o $@ $(CSRC)/archon_hip.hip

@@ -962,6 +962,14 @@ int archon_hip_release(int dev)
     return ARCHON_OK;
 }
 
+#ifdef ARCHON_EXPERIMENTS
+/* experiments library only (tools/): phase stamps of the last pass A ([0..31]) and pass B ([32..63]) launch */
+int archon_hip_exp_stamps(unsigned long long out[64])
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bs::g_pass_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? ARCHON_OK : ARCHON_E_HIP;
+}
+#endif
+
 int archon_hip_get_stats(int dev, archon_hip_stats *out)
 {
     if (!out) { set_error("null pointer"); return ARCHON_E_ARG; }
