@@ -968,6 +968,11 @@ int archon_hip_exp_stamps(unsigned long long out[64])
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(bs::g_pass_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? ARCHON_OK : ARCHON_E_HIP;
 }
+/* phase stamps of bucket 30000's workgroup in the last k_local_sort launch */
+int archon_hip_exp_ls_stamps(unsigned long long out[16])
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bs::g_ls_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? ARCHON_OK : ARCHON_E_HIP;
+}
 #endif
 
 int archon_hip_get_stats(int dev, archon_hip_stats *out)

@@ -20,3 +20,11 @@ for which, tag in ((0, "pass A"), (1, "pass B")):
     print("%s (%.3f ms): total %d cycles of wave 0 / workgroup 0" % (tag, st["ms_pass_text" if which == 0 else "ms_pass_rec"], tot))
     for nme, c in zip(names, v):
         print("   %-20s %9d  %5.1f %%" % (nme, c, 100.0 * c / tot))
+
+ls = (ctypes.c_ulonglong * 16)()
+assert pyarchon.lib().archon_hip_exp_ls_stamps(ls) == 0
+lsn = ["loads issued", "load wait+barrier", "count atomics", "barrier", "scan", "scatter rem", "barrier", "rank loops", "barrier", "write IC", "barrier", "output stores"]
+tot = sum(ls[i] for i in range(12)) or 1
+print("local sort (%.3f ms), bucket 30000: %d cycles" % (st["ms_local_sort"], tot))
+for i in range(12):
+    print("   %-20s %9d  %5.1f %%" % (lsn[i], ls[i], 100.0 * ls[i] / tot))
