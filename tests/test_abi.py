@@ -98,3 +98,27 @@ def test_synth_generators_are_deterministic():
     assert (S.gen_motif(3000)[:1000] == S.gen_motif(3000)[1000:2000]).all()
     # splitmix64 known value: first output for seed 0 is 0xE220A8397B1DCDAF
     assert int(S.splitmix64_words(0, 0, 1)[0]) == 0xE220A8397B1DCDAF
+
+
+REF_MAIN = "/root/reference/bwt/a7/src/main.cpp"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="reference tree not present (GPU box)")
+def test_reference_main_builds_against_the_shim(tmp_path):
+    """INTEGRATION.md option A, exactly as written: the reference's own caller (bwt/a7/src/main.cpp, unmodified, fed
+    through stdin so that its `#include "archon.h"` resolves to host/ref_shim/archon.h) compiles against the
+    MI355X-backed class Archon (reference interface: bwt/a7/src/archon.h:8-29) and links with libarchon_hip.so."""
+    pkg = os.path.join(ROOT, "dark-archon_amd")
+    obj, exe = str(tmp_path / "main_hip.o"), str(tmp_path / "main_hip")
+    with open(REF_MAIN, "rb") as src:
+        subprocess.run(["g++", "-O3", "-DNDEBUG", "-x", "c++", "-I" + os.path.join(pkg, "host", "ref_shim"), "-c", "-o", obj, "-"],
+                       stdin=src, check=True, capture_output=True)
+    subprocess.run(["g++", "-o", exe, obj, os.path.join(pkg, "host", "archon_host.cpp"), "-I" + os.path.join(ROOT, "include"),
+                    "-L" + pkg, "-larchon_hip", "-Wl,-rpath," + pkg], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 255 and "Usage: archon [e|d] <in> <out>" in r.stdout      # main.cpp:13-16: usage, return -1
+    # the reference's messages, then our compute entry point failing loudly without a GPU (no CPU fallback)
+    inp = tmp_path / "in.txt"
+    inp.write_bytes(b"abracadabra" * 10)
+    r = subprocess.run([exe, "e", str(inp), str(tmp_path / "out.bwt")], capture_output=True, text=True)
+    assert "Encoding SA..." in r.stdout
