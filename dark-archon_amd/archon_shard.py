@@ -41,6 +41,49 @@ def gather_payloads(dist, payload_t, rank, world, dst=0):
     return out
 
 
+class GatherPipe:
+    """The path's one exchange step as bench.py runs it: per step every rank contributes one fixed-size payload
+    (BWT || baseId of its block) to ONE gather on rank `dst`; the gather is asynchronous and double-buffered, so the
+    gather of step k (RCCL's own stream) overlaps the sort of step k+1.  `via_host` stages through host memory
+    (gloo rehearsal on fewer GPUs than ranks)."""
+
+    def __init__(self, dist, rank, world, payload_bytes, device, via_host=False, dst=0):
+        self.dist, self.rank, self.world, self.dst, self.via_host = dist, rank, world, dst, via_host
+        self.outs = [torch.empty(payload_bytes, dtype=torch.uint8, device=device) for _ in range(2)]
+        gdev = torch.device("cpu") if via_host else device
+        self.lists = [None, None]
+        if dist is not None and rank == dst:
+            self.lists = [[torch.empty(payload_bytes, dtype=torch.uint8, device=gdev) for _ in range(world)] for _ in range(2)]
+        self.pending = [None, None]
+        self.step_no = 0
+
+    def next_buffer(self):
+        """payload buffer of the coming step (waits until its previous gather has completed)"""
+        k = self.step_no & 1
+        if self.pending[k] is not None:
+            self.pending[k].wait()
+            self.pending[k] = None
+        return self.outs[k]
+
+    def submit(self):
+        k = self.step_no & 1
+        self.step_no += 1
+        if self.dist is not None:
+            src = self.outs[k].cpu() if self.via_host else self.outs[k]
+            self.pending[k] = self.dist.gather(src, self.lists[k], dst=self.dst, async_op=True)
+
+    def drain(self):
+        for k in range(2):
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+                self.pending[k] = None
+
+    def last(self):
+        """(own payload buffer, gathered list on dst) of the most recent step"""
+        k = (self.step_no - 1) & 1
+        return self.outs[k], self.lists[k]
+
+
 def run_sharded(dist, rank, world, blocks, forward_fn, device="cpu"):
     """Encode `blocks` (list of uint8 tensors, identical on every rank) block-sharded.
 

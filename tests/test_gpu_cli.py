@@ -178,3 +178,43 @@ def test_concurrent_host_threads(archon, oracle):
     for i, (P, B, b0) in enumerate(want):
         sa, bwt, base = got[i]
         assert (sa == P).all() and (bwt == B).all() and base == b0, i
+
+
+def test_config5_mixed_corpus_full_size(archon, tmp_path):
+    """BASELINE.json configs[4] at full size: a 1 GiB mixed corpus (4 x 256 MiB: text, random, DNA, 1000-byte motif)
+    -- every block forward + inverse through the C ABI with its BWT||baseId checked against the reference's digest
+    (tests/golden/golden_full.json), then the whole file through `archon e -b256m` / `archon d -b` and compared.
+    (The "MTF/entropy stage" of that config has no reference implementation: SURVEY.md 8(f) N4; see test_post_stage.)"""
+    import hashlib
+    import json
+    import torch
+    _build()
+    n = 256 << 20
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_full.json")) as f:
+        gold = {(c["shape"], c["block"]): c for c in json.load(f)["cases"]}
+    src = tmp_path / "corpus"
+    h_in = hashlib.sha256()
+    with open(src, "wb") as f:
+        for shape in ("text", "random", "dna", "motif"):
+            x = S.gen_shape(shape, n, block=0)
+            x.tofile(f)
+            h_in.update(x.tobytes())
+            x_t = torch.from_numpy(x).cuda()
+            out_t = torch.empty(n + 4, dtype=torch.uint8, device="cuda")
+            archon.forward_dev(x_t, None, out_t[:n], out_t[n:].view(torch.int32))
+            out = out_t.cpu().numpy()
+            assert hashlib.sha256(out.tobytes()).hexdigest() == gold[(shape, 0)]["sha256_bwt_base"], shape
+            back_t = torch.empty(n, dtype=torch.uint8, device="cuda")
+            archon.inverse_dev(out_t[:n], int(out[n:].view("<u4")[0]), back_t)
+            assert torch.equal(back_t, x_t), shape
+            del x, x_t, out_t, back_t, out
+    enc, dec = tmp_path / "corpus.ra", tmp_path / "corpus.out"
+    r = subprocess.run([EXE, "e", "-b256m", str(src), str(enc)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    r = subprocess.run([EXE, "d", "-b", str(enc), str(dec)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    h_out = hashlib.sha256()
+    with open(dec, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 24), b""):
+            h_out.update(chunk)
+    assert h_out.hexdigest() == h_in.hexdigest()
