@@ -98,7 +98,7 @@ static size_t forward_arena_bytes(uint32_t n)
     add(4 * (N + 1));               // rank
     add(4 * N);                     // sa (when the caller wants none)
     add(4 * N); add(4 * N); add(4 * N);       // v / gstart, keep, dst
-    for (int i = 0; i < 7; ++i) add(4 * N);   // upos, ug, uitem (double-buffered) + the initial rows
+    for (int i = 0; i < 8; ++i) add(4 * N);   // upos, ug, uitem (double-buffered), the initial rows, the round's group starts
     add(4 * scan_temp_words(N));
     add(4 * rs::status_words(n));
     add(4 * 8 * 256); add(4 * 8 * 256);       // ghist, gstart
@@ -115,7 +115,7 @@ struct FwdBuf {
     uint8_t *xa;
     uint64_t *keyA, *keyB;
     uint32_t *valA, *valB, *rank, *sa_own, *v, *keep, *dst;
-    uint32_t *upos[2], *ug[2], *uitem[2], *uinit, *rhist;
+    uint32_t *upos[2], *ug[2], *uitem[2], *uinit, *rhist, *vw;
     uint8_t *y;
     uint32_t *scan_tmp, *hist16, *small;
     bs::Prep *prep;
@@ -177,19 +177,56 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         }
     }
     int cur = 0;
-    if (m) {
-        // ranks are needed only now (4N random stores): every item, not just the tied ones
-        hipLaunchKernelGGL(fwd::k_scatter_rank, dim3(g256), dim3(256), 0, s, sa, B.v, n, sa, B.rank, B.keep);
-        ++c->launches;
-        hipLaunchKernelGGL(fwd::k_compact_first, dim3(g256), dim3(256), 0, s, B.keep, B.dst, B.v, sa, n, B.upos[0], B.ug[0],
-                           B.uitem[0]);
-        ARCHON_HIP_TRY(hipMemcpyAsync(B.uinit, B.upos[0], (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-        c->launches += 2;
-    }
     const uint32_t m0 = m;
     uint64_t *kT = B.keyA, *kS = B.keyB;
     uint32_t *vT = B.valA, *vS = B.valB;
     uint32_t h = h0;
+    if (m) {
+        hipLaunchKernelGGL(fwd::k_compact_first, dim3(g256), dim3(256), 0, s, B.keep, B.dst, B.v, sa, n, B.upos[0], B.ug[0],
+                           B.uitem[0]);
+        ARCHON_HIP_TRY(hipMemcpyAsync(B.uinit, B.upos[0], (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        ++c->launches;
+    }
+    // Text rounds: while few items are tied, key them on the next four bytes of the text instead of on ranks -- no
+    // inverse suffix array yet (its 4N-byte scatter costs more than a whole round on a small working set).  They stop
+    // as soon as a round fails to halve the working set (long repeats: doubling is what resolves those).
+    const bool text_ok = !getenv("ARCHON_NO_TEXT_ROUNDS");
+    while (m && text_ok && (uint64_t)m * 4 <= n && st.text_rounds < 4 && h < n) {
+        st.unresolved_total += m;
+        ++st.text_rounds;
+        const uint32_t gm = div_up(m, 256);
+        hipLaunchKernelGGL(fwd::k_gather_text, dim3(gm), dim3(256), 0, s, B.ug[cur], B.uitem[cur], d_x, h, m, kT, vT);
+        ARCHON_HIP_TRY(hipGetLastError());
+        bool b2 = false;
+        uint32_t passes = 0;
+        ARCHON_TRY(rs::sort_pairs(s, B.sc, kT, vT, kS, vS, m, 0xFFu, &b2, &passes, &c->launches));
+        uint64_t *kR = b2 ? kS : kT;
+        uint32_t *vR = b2 ? vS : vT;
+        hipLaunchKernelGGL(fwd::k_flag_round, dim3(gm), dim3(256), 0, s, kR, B.upos[cur], m, B.vw);
+        ARCHON_TRY(launch_scan<1>(s, B.vw, B.vw, m, B.scan_tmp, nullptr));
+        hipLaunchKernelGGL(fwd::k_round_update_text, dim3(gm), dim3(256), 0, s, vR, B.upos[cur], B.vw, m, sa, B.v, B.keep);
+        ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, m, B.scan_tmp, d_total));
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        c->launches += 9;
+        const uint32_t m2 = c->h_mail[0];
+        if (m2) {
+            hipLaunchKernelGGL(fwd::k_compact_round, dim3(gm), dim3(256), 0, s, B.keep, B.dst, B.upos[cur], B.vw, vR, m,
+                               B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1]);
+            ARCHON_HIP_TRY(hipGetLastError());
+            ++c->launches;
+        }
+        cur ^= 1;
+        h += 4;
+        const bool productive = (uint64_t)m2 * 2 <= m;
+        m = m2;
+        if (!productive) break;
+    }
+    if (m) {
+        // ranks are needed only now (4N random stores): every item, not just the tied ones
+        hipLaunchKernelGGL(fwd::k_scatter_rank, dim3(g256), dim3(256), 0, s, sa, B.v, n, sa, B.rank, B.keep);
+        ++c->launches;
+    }
     while (m) {
         st.unresolved_total += m;
         ++st.doubling_rounds;
@@ -201,16 +238,16 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         ARCHON_TRY(rs::sort_pairs(s, B.sc, kT, vT, kS, vS, m, 0xFFu, &b2, &passes, &c->launches));
         uint64_t *kR = b2 ? kS : kT;
         uint32_t *vR = b2 ? vS : vT;
-        hipLaunchKernelGGL(fwd::k_flag_round, dim3(gm), dim3(256), 0, s, kR, B.upos[cur], m, B.v);
-        ARCHON_TRY(launch_scan<1>(s, B.v, B.v, m, B.scan_tmp, nullptr));
-        hipLaunchKernelGGL(fwd::k_round_update, dim3(gm), dim3(256), 0, s, vR, B.upos[cur], B.v, m, sa, B.rank, B.keep);
+        hipLaunchKernelGGL(fwd::k_flag_round, dim3(gm), dim3(256), 0, s, kR, B.upos[cur], m, B.vw);
+        ARCHON_TRY(launch_scan<1>(s, B.vw, B.vw, m, B.scan_tmp, nullptr));
+        hipLaunchKernelGGL(fwd::k_round_update, dim3(gm), dim3(256), 0, s, vR, B.upos[cur], B.vw, m, sa, B.rank, B.keep);
         ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, m, B.scan_tmp, d_total));
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         c->launches += 9;
         const uint32_t m2 = c->h_mail[0];
         if (m2) {
-            hipLaunchKernelGGL(fwd::k_compact_round, dim3(gm), dim3(256), 0, s, B.keep, B.dst, B.upos[cur], B.v, vR, m,
+            hipLaunchKernelGGL(fwd::k_compact_round, dim3(gm), dim3(256), 0, s, B.keep, B.dst, B.upos[cur], B.vw, vR, m,
                                B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1]);
             ARCHON_HIP_TRY(hipGetLastError());
             ++c->launches;
@@ -260,6 +297,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         B.uitem[i] = c->alloc<uint32_t>(n);
     }
     B.uinit = c->alloc<uint32_t>(n);
+    B.vw = c->alloc<uint32_t>(n);                  // group starts of the working set inside a round (B.v stays the full table)
     B.scan_tmp = c->alloc<uint32_t>(scan_temp_words(n));
     B.sc.d_status = c->alloc<uint32_t>(rs::status_words(n));
     B.sc.d_ghist = c->alloc<uint32_t>(8 * 256);
@@ -505,25 +543,42 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         }
         e4 = e3;
     } else {
-        // ---- first stage for heavily skewed blocks: 7 LSB passes on packed 7-byte keys ----
+        // ---- first stage for heavily skewed blocks: LSB passes on packed 7-byte keys ----
         // alphabet compaction: with <= 16 distinct bytes the key holds 56/bits symbols
         const bool packed = sigma <= 16 && !getenv("ARCHON_NO_PACK");
+        // A periodic block (aaa..., abab..., a motif repeated: BASELINE.json configs[2]) needs no deep first stage:
+        // three key bytes separate the phases of the period, the run shortcut of general_stage settles the chains.
+        uint32_t key_bytes = fwd::kKeyBytes;
+        if (n >= (1u << 16) && !getenv("ARCHON_NO_PERIOD_PROBE")) {
+            uint32_t *pres = small + 610;
+            c->h_mail[0] = 0xFFFFFFFFu; c->h_mail[1] = 0;
+            ARCHON_HIP_TRY(hipMemcpyAsync(pres, c->h_mail, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(fwd::k_period_find, dim3(fwd::kPeriodSearch / 256), dim3(256), 0, s, d_x, n, pres);
+            hipLaunchKernelGGL(fwd::k_period_vote, dim3(fwd::kPeriodVotes / 256), dim3(256), 0, s, d_x, n, pres);
+            ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, pres, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            ARCHON_HIP_TRY(hipStreamSynchronize(s));
+            c->launches += 2;
+            if (c->h_mail[0] != 0xFFFFFFFFu && c->h_mail[1] * 10 >= fwd::kPeriodVotes * 9) key_bytes = 3;
+        }
         if (packed) {
             h0 = 56 / bits;
             hipLaunchKernelGGL(fwd::k_init_keys_packed, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, d_lut, bits, h0,
                                B.keyA, B.valA);
             st.alphabet_bits = bits;
+            h0 = (8 * key_bytes) / bits;            // symbols the sorted key bytes hold
         } else {
             hipLaunchKernelGGL(fwd::k_init_keys, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, B.keyA, B.valA);
+            h0 = key_bytes;
         }
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 2;
         bool in_b = false;
-        ARCHON_TRY(rs::sort_pairs(s, B.sc, B.keyA, B.valA, B.keyB, B.valB, n, 0xFEu, &in_b, &st.radix_passes, &c->launches, &pt));
+        const uint32_t pass_mask = (0xFFu << (8 - key_bytes)) & 0xFEu;          // the top key_bytes bytes; byte 0 is payload
+        ARCHON_TRY(rs::sort_pairs(s, B.sc, B.keyA, B.valA, B.keyB, B.valB, n, pass_mask, &in_b, &st.radix_passes, &c->launches, &pt));
         uint64_t *kS = in_b ? B.keyB : B.keyA;
         uint32_t *vS = in_b ? B.valB : B.valA;
         e2 = tm.mark();
-        hipLaunchKernelGGL(fwd::k_flag_boundaries, dim3(g256), dim3(256), 0, s, kS, n, B.v);
+        hipLaunchKernelGGL(fwd::k_flag_boundaries, dim3(g256), dim3(256), 0, s, kS, n, B.v, 8u * (8u - key_bytes));
         hipLaunchKernelGGL(fwd::k_bwt_from_keys, dim3(g256), dim3(256), 0, s, kS, vS, n, sa, d_bwt, d_base);
         c->launches += 2;
         e3 = e2;

@@ -146,7 +146,7 @@ typedef struct archon_hip_stats {
     uint32_t alphabet_bits;      /* 7-pass path: bits per symbol when the alphabet was compacted (0 = bytes) */
     uint32_t period;             /* long-repeat defence: the neighbour gap p it ran with (0 = not run) */
     uint32_t chain_items;        /* rows it settled without doubling */
-    uint32_t reserved2;
+    uint32_t text_rounds;        /* refinement rounds keyed on the next 4 text bytes (before any doubling round) */
 } archon_hip_stats;
 
 int archon_hip_get_stats(int dev, archon_hip_stats *out);
