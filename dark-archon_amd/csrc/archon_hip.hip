@@ -85,6 +85,28 @@ int ctx_ensure_arena(Ctx *c, size_t bytes)
     return ARCHON_OK;
 }
 
+int ctx_io(Ctx *c, int slot, size_t bytes, void **out)
+{
+    if (bytes > c->io_bytes[slot]) {
+        ARCHON_HIP_TRY(hipDeviceSynchronize());
+        if (c->io[slot]) {
+            if (slot == 1) { c->keep_bwt = nullptr; c->keep_n = 0; }
+            ARCHON_HIP_TRY(hipFree(c->io[slot]));
+            c->io[slot] = nullptr;
+            c->io_bytes[slot] = 0;
+        }
+        const size_t want = bytes + 256;
+        if (hipMalloc((void **)&c->io[slot], want) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("device staging allocation of %zu bytes failed", want);
+            return ARCHON_E_NOMEM;
+        }
+        c->io_bytes[slot] = want;
+    }
+    *out = c->io[slot];
+    return ARCHON_OK;
+}
+
 // ------------------------------------------------------------------ forward driver
 static size_t forward_arena_bytes(uint32_t n)
 {
@@ -661,33 +683,20 @@ int archon_hip_forward(const uint8_t *x, uint32_t n, uint32_t *sa_or_null, uint8
     ARCHON_HIP_TRY(hipSetDevice(dev));
     hipStream_t s = c->own_stream;
     uint8_t *d_x = nullptr, *d_bwt = nullptr;
-    uint32_t *d_sa = nullptr, *d_base = nullptr;
-    int rc = ARCHON_OK;
-    auto cleanup = [&]() {
-        if (d_x) (void)hipFree(d_x);
-        if (d_bwt) (void)hipFree(d_bwt);
-        if (d_sa) (void)hipFree(d_sa);
-        if (d_base) (void)hipFree(d_base);
-    };
-    if (hipMalloc((void **)&d_x, (size_t)n + 64) != hipSuccess || hipMalloc((void **)&d_bwt, (size_t)n + 64) != hipSuccess ||
-        hipMalloc((void **)&d_base, 256) != hipSuccess ||
-        (sa_or_null && hipMalloc((void **)&d_sa, (size_t)n * 4) != hipSuccess)) {
-        (void)hipGetLastError();
-        cleanup();
-        set_error("device allocation failed for block of %u bytes", n);
-        return ARCHON_E_NOMEM;
-    }
-    hipError_t e = hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) rc = forward_run(c, s, d_x, n, d_sa, d_bwt, d_base);
-    if (e == hipSuccess && rc == ARCHON_OK) {
-        e = hipMemcpyAsync(bwt, d_bwt, n, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(base_id, d_base, 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess && sa_or_null) e = hipMemcpyAsync(sa_or_null, d_sa, (size_t)n * 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-    }
-    cleanup();
-    if (e != hipSuccess) { set_error("HIP copy failed: %s", hipGetErrorString(e)); return ARCHON_E_HIP; }
-    return rc;
+    uint32_t *d_sa = nullptr;
+    ARCHON_TRY(ctx_io(c, 0, (size_t)n + 64, (void **)&d_x));
+    ARCHON_TRY(ctx_io(c, 1, (size_t)n + 64, (void **)&d_bwt));
+    if (sa_or_null) ARCHON_TRY(ctx_io(c, 2, (size_t)n * 4, (void **)&d_sa));
+    c->keep_bwt = nullptr; c->keep_n = 0;            // the staging BWT is overwritten
+    uint32_t *d_base = c->d_mail + 620;
+    ARCHON_HIP_TRY(hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s));
+    ARCHON_TRY(forward_run(c, s, d_x, n, d_sa, d_bwt, d_base));
+    // BWT first (the block coder's enWrite can start on it), then the 4N bytes of the suffix array
+    ARCHON_HIP_TRY(hipMemcpyAsync(bwt, d_bwt, n, hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipMemcpyAsync(base_id, d_base, 4, hipMemcpyDeviceToHost, s));
+    if (sa_or_null) ARCHON_HIP_TRY(hipMemcpyAsync(sa_or_null, d_sa, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    return ARCHON_OK;
 }
 
 int archon_hip_forward_keep(const uint8_t *x, uint32_t n, uint32_t *sa_or_null, uint32_t *base_id, int dev)
@@ -699,34 +708,21 @@ int archon_hip_forward_keep(const uint8_t *x, uint32_t n, uint32_t *sa_or_null, 
     std::lock_guard<std::mutex> lk(c->mu);
     ARCHON_HIP_TRY(hipSetDevice(dev));
     hipStream_t s = c->own_stream;
-    if (c->keep_bwt) { (void)hipFree(c->keep_bwt); c->keep_bwt = nullptr; c->keep_n = 0; }
-    uint8_t *d_x = nullptr;
-    uint32_t *d_sa = nullptr, *d_base = nullptr;
-    auto cleanup = [&]() {
-        if (d_x) (void)hipFree(d_x);
-        if (d_sa) (void)hipFree(d_sa);
-        if (d_base) (void)hipFree(d_base);
-    };
-    if (hipMalloc((void **)&d_x, (size_t)n + 64) != hipSuccess || hipMalloc((void **)&c->keep_bwt, (size_t)n + 64) != hipSuccess ||
-        hipMalloc((void **)&d_base, 256) != hipSuccess ||
-        (sa_or_null && hipMalloc((void **)&d_sa, (size_t)n * 4) != hipSuccess)) {
-        (void)hipGetLastError();
-        cleanup();
-        set_error("device allocation failed for block of %u bytes", n);
-        return ARCHON_E_NOMEM;
-    }
-    int rc = ARCHON_OK;
-    hipError_t e = hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) rc = forward_run(c, s, d_x, n, d_sa, c->keep_bwt, d_base);
-    if (e == hipSuccess && rc == ARCHON_OK) {
-        e = hipMemcpyAsync(base_id, d_base, 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess && sa_or_null) e = hipMemcpyAsync(sa_or_null, d_sa, (size_t)n * 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-    }
-    cleanup();
-    if (e != hipSuccess) { set_error("HIP copy failed: %s", hipGetErrorString(e)); return ARCHON_E_HIP; }
-    if (rc == ARCHON_OK) c->keep_n = n;
-    return rc;
+    uint8_t *d_x = nullptr, *d_bwt = nullptr;
+    uint32_t *d_sa = nullptr;
+    ARCHON_TRY(ctx_io(c, 0, (size_t)n + 64, (void **)&d_x));
+    ARCHON_TRY(ctx_io(c, 1, (size_t)n + 64, (void **)&d_bwt));
+    if (sa_or_null) ARCHON_TRY(ctx_io(c, 2, (size_t)n * 4, (void **)&d_sa));
+    c->keep_bwt = nullptr; c->keep_n = 0;
+    uint32_t *d_base = c->d_mail + 620;
+    ARCHON_HIP_TRY(hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s));
+    ARCHON_TRY(forward_run(c, s, d_x, n, d_sa, d_bwt, d_base));
+    ARCHON_HIP_TRY(hipMemcpyAsync(base_id, d_base, 4, hipMemcpyDeviceToHost, s));
+    if (sa_or_null) ARCHON_HIP_TRY(hipMemcpyAsync(sa_or_null, d_sa, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    c->keep_bwt = d_bwt;
+    c->keep_n = n;
+    return ARCHON_OK;
 }
 
 int archon_hip_read_bwt(int dev, uint32_t offset, uint32_t len, uint8_t *dst)
@@ -778,23 +774,14 @@ int archon_hip_inverse(const uint8_t *bwt, uint32_t n, uint32_t base_id, uint8_t
     ARCHON_HIP_TRY(hipSetDevice(dev));
     hipStream_t s = c->own_stream;
     uint8_t *d_in = nullptr, *d_out = nullptr;
-    if (hipMalloc((void **)&d_in, (size_t)n + 64) != hipSuccess || hipMalloc((void **)&d_out, (size_t)n + 64) != hipSuccess) {
-        (void)hipGetLastError();
-        if (d_in) (void)hipFree(d_in);
-        set_error("device allocation failed for block of %u bytes", n);
-        return ARCHON_E_NOMEM;
-    }
-    int rc = ARCHON_OK;
-    hipError_t e = hipMemcpyAsync(d_in, bwt, n, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) rc = inverse_run(c, s, d_in, n, base_id, d_out);
-    if (e == hipSuccess && rc == ARCHON_OK) {
-        e = hipMemcpyAsync(x_out, d_out, n, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-    }
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
-    if (e != hipSuccess) { set_error("HIP copy failed: %s", hipGetErrorString(e)); return ARCHON_E_HIP; }
-    return rc;
+    ARCHON_TRY(ctx_io(c, 0, (size_t)n + 64, (void **)&d_in));
+    ARCHON_TRY(ctx_io(c, 1, (size_t)n + 64, (void **)&d_out));
+    c->keep_bwt = nullptr; c->keep_n = 0;
+    ARCHON_HIP_TRY(hipMemcpyAsync(d_in, bwt, n, hipMemcpyHostToDevice, s));
+    ARCHON_TRY(inverse_run(c, s, d_in, n, base_id, d_out));
+    ARCHON_HIP_TRY(hipMemcpyAsync(x_out, d_out, n, hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    return ARCHON_OK;
 }
 
 int archon_hip_hist256_dev(const uint8_t *d_x, size_t n, uint32_t *d_out256, int dev, void *stream)
@@ -853,21 +840,11 @@ int archon_hip_validate(const uint8_t *x, uint32_t n, const uint32_t *sa, int de
     hipStream_t s = c->own_stream;
     uint8_t *d_x = nullptr;
     uint32_t *d_sa = nullptr;
-    if (hipMalloc((void **)&d_x, (size_t)n + 64) != hipSuccess || hipMalloc((void **)&d_sa, (size_t)n * 4) != hipSuccess) {
-        (void)hipGetLastError();
-        if (d_x) (void)hipFree(d_x);
-        set_error("device allocation failed");
-        return ARCHON_E_NOMEM;
-    }
-    int rc = ARCHON_E_HIP;
-    if (hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s) == hipSuccess &&
-        hipMemcpyAsync(d_sa, sa, (size_t)n * 4, hipMemcpyHostToDevice, s) == hipSuccess)
-        rc = validate_run(c, s, d_x, n, d_sa);
-    else
-        set_error("HIP copy failed");
-    (void)hipFree(d_x);
-    (void)hipFree(d_sa);
-    return rc;
+    ARCHON_TRY(ctx_io(c, 0, (size_t)n + 64, (void **)&d_x));      // (slot 1 may hold the BWT kept for enWrite: untouched)
+    ARCHON_TRY(ctx_io(c, 2, (size_t)n * 4, (void **)&d_sa));
+    ARCHON_HIP_TRY(hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s));
+    ARCHON_HIP_TRY(hipMemcpyAsync(d_sa, sa, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    return validate_run(c, s, d_x, n, d_sa);
 }
 
 static int sa_to_bwt_run(Ctx *c, hipStream_t s, const uint8_t *d_x, uint32_t n, const uint32_t *d_sa, uint8_t *d_bwt,
@@ -912,31 +889,17 @@ int archon_hip_sa_to_bwt(const uint8_t *x, uint32_t n, const uint32_t *sa, uint8
     hipStream_t s = c->own_stream;
     uint8_t *d_x = nullptr, *d_bwt = nullptr;
     uint32_t *d_sa = nullptr;
-    int rc = ARCHON_E_NOMEM;
-    if (hipMalloc((void **)&d_x, (size_t)n + 64) == hipSuccess && hipMalloc((void **)&d_bwt, (size_t)n + 64) == hipSuccess &&
-        hipMalloc((void **)&d_sa, (size_t)n * 4 + 64) == hipSuccess) {
-        rc = ARCHON_E_HIP;
-        if (hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s) == hipSuccess &&
-            hipMemcpyAsync(d_sa, sa, (size_t)n * 4, hipMemcpyHostToDevice, s) == hipSuccess) {
-            rc = sa_to_bwt_run(c, s, d_x, n, d_sa, d_bwt, c->d_mail + 610);
-            if (rc == ARCHON_OK &&
-                (hipMemcpyAsync(bwt, d_bwt, n, hipMemcpyDeviceToHost, s) != hipSuccess ||
-                 hipMemcpyAsync(base_id, c->d_mail + 610, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                 hipStreamSynchronize(s) != hipSuccess)) {
-                set_error("HIP copy failed");
-                rc = ARCHON_E_HIP;
-            }
-        } else {
-            set_error("HIP copy failed");
-        }
-    } else {
-        (void)hipGetLastError();
-        set_error("device allocation failed");
-    }
-    if (d_x) (void)hipFree(d_x);
-    if (d_bwt) (void)hipFree(d_bwt);
-    if (d_sa) (void)hipFree(d_sa);
-    return rc;
+    ARCHON_TRY(ctx_io(c, 0, (size_t)n + 64, (void **)&d_x));
+    ARCHON_TRY(ctx_io(c, 1, (size_t)n + 64, (void **)&d_bwt));
+    ARCHON_TRY(ctx_io(c, 2, (size_t)n * 4 + 64, (void **)&d_sa));
+    c->keep_bwt = nullptr; c->keep_n = 0;
+    ARCHON_HIP_TRY(hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s));
+    ARCHON_HIP_TRY(hipMemcpyAsync(d_sa, sa, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    ARCHON_TRY(sa_to_bwt_run(c, s, d_x, n, d_sa, d_bwt, c->d_mail + 610));
+    ARCHON_HIP_TRY(hipMemcpyAsync(bwt, d_bwt, n, hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipMemcpyAsync(base_id, c->d_mail + 610, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    return ARCHON_OK;
 }
 
 int archon_hip_radix_scatter_dev(const uint8_t *d_src, size_t n, uint8_t *d_dst, int dev, void *stream)
@@ -1005,7 +968,8 @@ int archon_hip_release(int dev)
         (void)hipSetDevice(dev);
         (void)hipDeviceSynchronize();
         if (c->arena) (void)hipFree(c->arena);
-        if (c->keep_bwt) (void)hipFree(c->keep_bwt);
+        for (int i = 0; i < Ctx::kIo; ++i)
+            if (c->io[i]) (void)hipFree(c->io[i]);
         if (c->d_mail) (void)hipFree(c->d_mail);
         if (c->h_mail) (void)hipHostFree(c->h_mail);
         for (int i = 0; i < Ctx::kEvents; ++i)

@@ -6,10 +6,19 @@
 //   the 4-byte primary index; every block but the last has n == block size, and a shorter (possibly empty)
 //   block ends the file -- exactly what x3's reader loop `while(n==fsize)` expects.
 // The block payload is the a7 transform (BWT || baseId in a7 order), not x3's own sort order.
+//
+// x3 reads, transforms and writes one block after the other (archon.c:120-142).  Here the three steps are a
+// pipeline over a ring of pinned host slots: a reader thread fills slot b mod S with block b, one worker thread per
+// GPU (block b -> GPU b mod G, the sharding rule of dark-archon_amd/archon_shard.py) runs the transform
+// (H2D + kernels + D2H through the C ABI), a writer thread emits the blocks in order -- so the fread of block k+1
+// and the fwrite of block k-1 overlap the GPU's work on block k.
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -18,81 +27,177 @@
 
 static const unsigned short kSig = 0x5241;   // 'RA' as x3 writes it
 
+namespace {
+
+enum SlotState { kFree, kFilled, kDone };
+
 struct Slot {
-    std::vector<byte> in, out;
+    byte *in = nullptr, *out = nullptr;
+    bool pinned = false;
+    size_t n = 0;            // payload bytes of the block in the slot
     t_index base = 0;
-    int rc = 0;
+    SlotState state = kFree;
+    bool last = false;
 };
+
+struct Pipe {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Slot> slot;
+    long nblocks = -1;       // known once the reader has seen the short block
+    int rc = 0;              // first error; everybody stops
+
+    bool alloc(int nslots, size_t bytes)
+    {
+        slot.resize(nslots);
+        for (Slot &s : slot) {
+            s.in = static_cast<byte *>(archon_hip_host_alloc(bytes));
+            s.out = static_cast<byte *>(archon_hip_host_alloc(bytes));
+            s.pinned = s.in && s.out;
+            if (!s.pinned) {
+                if (s.in) archon_hip_host_free(s.in);
+                if (s.out) archon_hip_host_free(s.out);
+                s.in = static_cast<byte *>(malloc(bytes));
+                s.out = static_cast<byte *>(malloc(bytes));
+            }
+            if (!s.in || !s.out) return false;
+        }
+        return true;
+    }
+    ~Pipe()
+    {
+        for (Slot &s : slot) {
+            if (s.pinned) { archon_hip_host_free(s.in); archon_hip_host_free(s.out); }
+            else { free(s.in); free(s.out); }
+        }
+    }
+    // waits until slot (b mod S) reaches `want`; false when the pipeline has failed or block b does not exist
+    bool wait(long b, SlotState want, Slot **out)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        Slot &s = slot[(size_t)(b % (long)slot.size())];
+        cv.wait(lk, [&] { return rc != 0 || (nblocks >= 0 && b >= nblocks) || s.state == want; });
+        if (rc != 0 || (nblocks >= 0 && b >= nblocks)) return false;
+        *out = &s;
+        return true;
+    }
+    void set(Slot *s, SlotState st)
+    {
+        { std::lock_guard<std::mutex> lk(mu); s->state = st; }
+        cv.notify_all();
+    }
+    void fail(int code)
+    {
+        { std::lock_guard<std::mutex> lk(mu); if (!rc) rc = code; }
+        cv.notify_all();
+    }
+    void total(long n)
+    {
+        { std::lock_guard<std::mutex> lk(mu); nblocks = n; }
+        cv.notify_all();
+    }
+};
+
+// the worker of GPU `dev`: blocks dev, dev + G, dev + 2G, ...
+template <class Work>
+void worker_loop(Pipe &p, int dev, int ndev, Work work)
+{
+    for (long b = dev;; b += ndev) {
+        Slot *s;
+        if (!p.wait(b, kFilled, &s)) return;
+        const int rc = s->n ? work(*s, dev) : 0;
+        if (rc) { p.fail(rc); return; }
+        p.set(s, kDone);
+    }
+}
+
+}  // namespace
 
 int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev)
 {
     if (ndev < 1) return -4;
     fwrite(&kSig, 2, 1, fo);
     fwrite(&bsize, 4, 1, fo);
-    std::vector<Slot> slot(ndev);
-    bool last_seen = false;
-    while (!last_seen) {
-        int used = 0;
-        for (; used < ndev && !last_seen; ++used) {
-            slot[used].in.resize(bsize);
-            const size_t n = fread(slot[used].in.data(), 1, bsize, fi);
-            slot[used].in.resize(n);
-            if (n < bsize) last_seen = true;
+    Pipe p;
+    if (!p.alloc(3 * ndev, (size_t)bsize + 4)) return ARCHON_E_NOMEM;
+
+    std::thread reader([&] {
+        for (long b = 0;; ++b) {
+            Slot *s;
+            if (!p.wait(b, kFree, &s)) return;
+            s->n = fread(s->in, 1, bsize, fi);
+            s->last = s->n < bsize;
+            const bool last = s->last;
+            p.set(s, kFilled);
+            if (last) { p.total(b + 1); return; }
         }
-        std::vector<std::thread> th;
-        for (int k = 0; k < used; ++k)
-            th.emplace_back([&, k]() {
-                Slot &s = slot[k];
-                s.rc = 0;
-                s.base = 0;
-                s.out.resize(s.in.size());
-                if (!s.in.empty())
-                    s.rc = archon_hip_forward(s.in.data(), (uint32_t)s.in.size(), NULL, s.out.data(), &s.base, k);
+    });
+    std::vector<std::thread> workers;
+    for (int d = 0; d < ndev; ++d)
+        workers.emplace_back([&, d] {
+            worker_loop(p, d, ndev, [](Slot &s, int dev) {
+                return archon_hip_forward(s.in, (uint32_t)s.n, NULL, s.out, &s.base, dev);
             });
-        for (auto &t : th) t.join();
-        for (int k = 0; k < used; ++k) {
-            if (slot[k].rc) return slot[k].rc;
-            if (!slot[k].out.empty()) fwrite(slot[k].out.data(), 1, slot[k].out.size(), fo);
-            fwrite(&slot[k].base, 4, 1, fo);
+        });
+    std::thread writer([&] {
+        for (long b = 0;; ++b) {
+            Slot *s;
+            if (!p.wait(b, kDone, &s)) return;
+            if (s->n && fwrite(s->out, 1, s->n, fo) != s->n) { p.fail(-3); return; }
+            const t_index base = s->n ? s->base : 0;
+            if (fwrite(&base, 4, 1, fo) != 1) { p.fail(-3); return; }
+            p.set(s, kFree);
         }
-    }
-    return 0;
+    });
+    reader.join();
+    for (auto &t : workers) t.join();
+    writer.join();
+    return p.rc;
 }
 
-int archon_container_decode(FILE *fi, FILE *fo, int ndev)
+int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out)
 {
     if (ndev < 1) return -4;
     unsigned short sig = 0;
     uint32_t bsize = 0;
     if (fread(&sig, 2, 1, fi) != 1 || sig != kSig) return -3;
     if (fread(&bsize, 4, 1, fi) != 1 || bsize < 8 || bsize > (1u << 28)) return -3;
-    std::vector<Slot> slot(ndev);
-    bool last_seen = false;
-    while (!last_seen) {
-        int used = 0;
-        for (; used < ndev && !last_seen; ++used) {
-            slot[used].in.resize((size_t)bsize + 4);
-            const size_t got = fread(slot[used].in.data(), 1, (size_t)bsize + 4, fi);
-            if (got < 4) return -2;
-            const size_t n = got - 4;
-            memcpy(&slot[used].base, slot[used].in.data() + n, 4);
-            slot[used].in.resize(n);
-            if (n < bsize) last_seen = true;
+    if (bsize_out) *bsize_out = bsize;
+    Pipe p;
+    if (!p.alloc(3 * ndev, (size_t)bsize + 4)) return ARCHON_E_NOMEM;
+
+    std::thread reader([&] {
+        for (long b = 0;; ++b) {
+            Slot *s;
+            if (!p.wait(b, kFree, &s)) return;
+            const size_t got = fread(s->in, 1, (size_t)bsize + 4, fi);
+            if (got < 4) { p.fail(-2); return; }
+            s->n = got - 4;
+            memcpy(&s->base, s->in + s->n, 4);
+            s->last = s->n < bsize;
+            if (s->n && s->base >= s->n) { p.fail(-2); return; }
+            const bool last = s->last;
+            p.set(s, kFilled);
+            if (last) { p.total(b + 1); return; }
         }
-        std::vector<std::thread> th;
-        for (int k = 0; k < used; ++k)
-            th.emplace_back([&, k]() {
-                Slot &s = slot[k];
-                s.rc = 0;
-                s.out.resize(s.in.size());
-                if (!s.in.empty())
-                    s.rc = archon_hip_inverse(s.in.data(), (uint32_t)s.in.size(), s.base, s.out.data(), k);
+    });
+    std::vector<std::thread> workers;
+    for (int d = 0; d < ndev; ++d)
+        workers.emplace_back([&, d] {
+            worker_loop(p, d, ndev, [](Slot &s, int dev) {
+                return archon_hip_inverse(s.in, (uint32_t)s.n, s.base, s.out, dev);
             });
-        for (auto &t : th) t.join();
-        for (int k = 0; k < used; ++k) {
-            if (slot[k].rc) return slot[k].rc;
-            if (!slot[k].out.empty()) fwrite(slot[k].out.data(), 1, slot[k].out.size(), fo);
+        });
+    std::thread writer([&] {
+        for (long b = 0;; ++b) {
+            Slot *s;
+            if (!p.wait(b, kDone, &s)) return;
+            if (s->n && fwrite(s->out, 1, s->n, fo) != s->n) { p.fail(-3); return; }
+            p.set(s, kFree);
         }
-    }
-    return 0;
+    });
+    reader.join();
+    for (auto &t : workers) t.join();
+    writer.join();
+    return p.rc;
 }

@@ -18,7 +18,7 @@
 static const char sUsage[] = "Usage: archon [e|d] <in> <out>\n";
 
 int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev);
-int archon_container_decode(FILE *fi, FILE *fo, int ndev);
+int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out);
 
 static double now_sec()
 {
@@ -47,7 +47,7 @@ int main(const int argc, const char *const argv[])
         int ndev = archon_hip_device_count();
         if (const char *e = getenv("ARCHON_DEVICES")) { const int want = atoi(e); if (want > 0 && want < ndev) ndev = want; }
         const double t0c = now_sec();
-        const int rc = argv[1][0] == 'e' ? archon_container_encode(fi, fo, fsize, ndev) : archon_container_decode(fi, fo, ndev);
+        const int rc = argv[1][0] == 'e' ? archon_container_encode(fi, fo, fsize, ndev) : archon_container_decode(fi, fo, ndev, &fsize);
         fclose(fi);
         fclose(fo);
         if (rc) {
