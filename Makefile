@@ -20,15 +20,15 @@ $(LIB): $(CSRC)/archon_hip.hip $(wildcard $(CSRC)/*.hiph) include/archon_hip.h
 host: $(PKG)/libarchon.so
 
 # the block-coder object (include/archon.h) as a shared library for FFI callers
-$(PKG)/libarchon.so: $(PKG)/host/archon_host.cpp $(PKG)/host/archon_host.h include/archon.h $(LIB)
-	$(CXX) -O2 -std=c++17 -Wall -fPIC -shared -Iinclude -o $@ $(PKG)/host/archon_host.cpp \
+$(PKG)/libarchon.so: $(PKG)/host/archon_host.cpp $(PKG)/host/archon_post.cpp $(PKG)/host/archon_host.h include/archon.h $(LIB)
+	$(CXX) -O2 -std=c++17 -Wall -fPIC -shared -Iinclude -o $@ $(PKG)/host/archon_host.cpp $(PKG)/host/archon_post.cpp \
 	    -L$(PKG) -larchon_hip -Wl,-rpath,'$$ORIGIN'
 
 cli: bin/archon
 
-bin/archon: $(PKG)/host/archon_host.cpp $(PKG)/host/archon_main.cpp $(PKG)/host/archon_container.cpp $(PKG)/host/archon_host.h include/archon.h $(LIB)
+bin/archon: $(PKG)/host/archon_host.cpp $(PKG)/host/archon_main.cpp $(PKG)/host/archon_container.cpp $(PKG)/host/archon_post.cpp $(PKG)/host/archon_host.h include/archon.h $(LIB)
 	@mkdir -p bin
-	$(CXX) -O2 -std=c++17 -Wall -pthread -Iinclude -o $@ $(PKG)/host/archon_main.cpp $(PKG)/host/archon_host.cpp $(PKG)/host/archon_container.cpp \
+	$(CXX) -O2 -std=c++17 -Wall -pthread -Iinclude -o $@ $(PKG)/host/archon_main.cpp $(PKG)/host/archon_host.cpp $(PKG)/host/archon_container.cpp $(PKG)/host/archon_post.cpp \
 	    -L$(PKG) -larchon_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)'
 
 oracle:

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -25,7 +26,14 @@
 #include "archon_host.h"
 #include "../../include/archon_hip.h"
 
-static const unsigned short kSig = 0x5241;   // 'RA' as x3 writes it
+static const unsigned short kSig = 0x5241;       // 'RA' as x3 writes it
+static const unsigned short kSigPost = 0x4D52;   // 'RM': blocks carry the MTF + entropy stage (archon_post.cpp, parity unpinned)
+
+extern "C" {
+size_t archon_post_bound(size_t n);
+size_t archon_post_encode(const uint8_t *bwt, size_t n, uint8_t *out);
+int archon_post_decode(const uint8_t *in, size_t in_bytes, uint8_t *bwt, size_t n);
+}
 
 namespace {
 
@@ -111,12 +119,82 @@ void worker_loop(Pipe &p, int dev, int ndev, Work work)
     }
 }
 
+// ---- post stage (no reference implementation): a block's BWT is cut into pieces of 4 MiB that are
+// coded independently (MTF restarts per piece) by a pool of host threads.
+// Packed block: u32 pieces | u32 packed bytes of each piece | the pieces.
+constexpr size_t kPiece = 4u << 20;
+
+void post_pack(const byte *bwt, size_t n, std::vector<byte> &out)
+{
+    const size_t np = (n + kPiece - 1) / kPiece;
+    std::vector<std::vector<byte>> part(np);
+    std::vector<std::thread> th;
+    const unsigned nth = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 32u));
+    for (unsigned t = 0; t < nth; ++t)
+        th.emplace_back([&, t] {
+            for (size_t k = t; k < np; k += nth) {
+                const size_t len = std::min(kPiece, n - k * kPiece);
+                part[k].resize(archon_post_bound(len));
+                part[k].resize(archon_post_encode(bwt + k * kPiece, len, part[k].data()));
+            }
+        });
+    for (auto &t : th) t.join();
+    size_t total = 4 + 4 * np;
+    for (auto &v : part) total += v.size();
+    out.resize(total);
+    const uint32_t np32 = (uint32_t)np;
+    memcpy(out.data(), &np32, 4);
+    size_t off = 4 + 4 * np;
+    for (size_t k = 0; k < np; ++k) {
+        const uint32_t sz = (uint32_t)part[k].size();
+        memcpy(out.data() + 4 + 4 * k, &sz, 4);
+        memcpy(out.data() + off, part[k].data(), sz);
+        off += sz;
+    }
+}
+
+// returns the block length n, or -1 on a malformed stream; bwt must hold `cap` bytes
+long post_unpack(const byte *in, size_t in_bytes, byte *bwt, size_t cap)
+{
+    if (in_bytes < 4) return -1;
+    uint32_t np;
+    memcpy(&np, in, 4);
+    if ((size_t)np > cap / kPiece + 1 || in_bytes < 4 + 4 * (size_t)np) return -1;
+    std::vector<size_t> off(np + 1), len(np);
+    off[0] = 4 + 4 * (size_t)np;
+    size_t n = 0;
+    for (uint32_t k = 0; k < np; ++k) {
+        uint32_t sz;
+        memcpy(&sz, in + 4 + 4 * k, 4);
+        off[k + 1] = off[k] + sz;
+        if (off[k + 1] > in_bytes || sz < 4) return -1;
+        uint32_t plen;
+        memcpy(&plen, in + off[k], 4);
+        if (plen > kPiece || (k + 1 < np && plen != kPiece)) return -1;
+        len[k] = plen;
+        n += plen;
+    }
+    if (n > cap) return -1;
+    std::vector<int> rc(np, 0);
+    std::vector<std::thread> th;
+    const unsigned nth = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 32u));
+    for (unsigned t = 0; t < nth; ++t)
+        th.emplace_back([&, t] {
+            for (size_t k = t; k < np; k += nth)
+                rc[k] = archon_post_decode(in + off[k], off[k + 1] - off[k], bwt + k * kPiece, len[k]);
+        });
+    for (auto &t : th) t.join();
+    for (int r : rc)
+        if (r) return -1;
+    return (long)n;
+}
+
 }  // namespace
 
-int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev)
+int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev, int post)
 {
     if (ndev < 1) return -4;
-    fwrite(&kSig, 2, 1, fo);
+    fwrite(post ? &kSigPost : &kSig, 2, 1, fo);
     fwrite(&bsize, 4, 1, fo);
     Pipe p;
     if (!p.alloc(3 * ndev, (size_t)bsize + 4)) return ARCHON_E_NOMEM;
@@ -143,7 +221,12 @@ int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev)
         for (long b = 0;; ++b) {
             Slot *s;
             if (!p.wait(b, kDone, &s)) return;
-            if (s->n && fwrite(s->out, 1, s->n, fo) != s->n) { p.fail(-3); return; }
+            if (post) {                                  // u32 packed bytes | packed block | index
+                std::vector<byte> packed;
+                post_pack(s->out, s->n, packed);
+                const uint32_t sz = (uint32_t)packed.size();
+                if (fwrite(&sz, 4, 1, fo) != 1 || fwrite(packed.data(), 1, sz, fo) != sz) { p.fail(-3); return; }
+            } else if (s->n && fwrite(s->out, 1, s->n, fo) != s->n) { p.fail(-3); return; }
             const t_index base = s->n ? s->base : 0;
             if (fwrite(&base, 4, 1, fo) != 1) { p.fail(-3); return; }
             p.set(s, kFree);
@@ -160,7 +243,8 @@ int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out)
     if (ndev < 1) return -4;
     unsigned short sig = 0;
     uint32_t bsize = 0;
-    if (fread(&sig, 2, 1, fi) != 1 || sig != kSig) return -3;
+    if (fread(&sig, 2, 1, fi) != 1 || (sig != kSig && sig != kSigPost)) return -3;
+    const bool post = sig == kSigPost;
     if (fread(&bsize, 4, 1, fi) != 1 || bsize < 8 || bsize > (1u << 28)) return -3;
     if (bsize_out) *bsize_out = bsize;
     Pipe p;
@@ -170,10 +254,20 @@ int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out)
         for (long b = 0;; ++b) {
             Slot *s;
             if (!p.wait(b, kFree, &s)) return;
-            const size_t got = fread(s->in, 1, (size_t)bsize + 4, fi);
-            if (got < 4) { p.fail(-2); return; }
-            s->n = got - 4;
-            memcpy(&s->base, s->in + s->n, 4);
+            if (post) {
+                uint32_t sz = 0;
+                if (fread(&sz, 4, 1, fi) != 1 || sz > archon_post_bound(bsize) + 4 * (bsize / kPiece + 2)) { p.fail(-2); return; }
+                std::vector<byte> packed(sz);
+                if (fread(packed.data(), 1, sz, fi) != sz || fread(&s->base, 4, 1, fi) != 1) { p.fail(-2); return; }
+                const long n = post_unpack(packed.data(), sz, s->in, bsize);
+                if (n < 0) { p.fail(-2); return; }
+                s->n = (size_t)n;
+            } else {
+                const size_t got = fread(s->in, 1, (size_t)bsize + 4, fi);
+                if (got < 4) { p.fail(-2); return; }
+                s->n = got - 4;
+                memcpy(&s->base, s->in + s->n, 4);
+            }
             s->last = s->n < bsize;
             if (s->n && s->base >= s->n) { p.fail(-2); return; }
             const bool last = s->last;

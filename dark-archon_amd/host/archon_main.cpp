@@ -3,6 +3,8 @@
 // kvark/dark-archon bwt/a7/src/main.cpp:10-75 (-1 usage, -2 cannot open input /
 // too short, -3 empty input or cannot open output); adds -4 for a GPU-side error.
 // NO_VALIDATE / NO_WRITE keep their reference meaning (main.cpp:42,47).
+// Extension (PARITY UNPINNED -- the reference has no such stage): `archon e -m -b<size> <in> <out>`
+// adds move-to-front + zero runs + order-0 Huffman per block (archon_post.cpp); `archon d -b` decodes either kind.
 // Extension: `archon e|d -b<size>[k|m] <in> <out>` reads/writes ArchonX3's multi-block
 // container (bwt/final/x3/archon.c:100-110: default 4m, 8 <= size <= 256m) and spreads the blocks over the
 // GPUs of the node; `d -b` takes the block size from the file header.
@@ -17,7 +19,7 @@
 
 static const char sUsage[] = "Usage: archon [e|d] <in> <out>\n";
 
-int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev);
+int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev, int post);
 int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out);
 
 static double now_sec()
@@ -32,22 +34,26 @@ int main(const int argc, const char *const argv[])
     FILE *fx;
     bool mode;
     printf("Archon-7 format, MI355X (gfx950) back end\n");
-    if (argc == 5 && argv[2][0] == '-' && argv[2][1] == 'b' && (!strcmp(argv[1], "e") || !strcmp(argv[1], "d"))) {
+    // `-m` in front of `-b`: blocks additionally go through the MTF + entropy stage (archon_post.cpp; no reference
+    // implementation -- parity unpinned); the decoder recognises such containers by their signature
+    const bool post = argc == 6 && !strcmp(argv[2], "-m");
+    const char *const *av = post ? argv + 1 : argv;
+    if ((argc == 5 || post) && av[2][0] == '-' && av[2][1] == 'b' && (!strcmp(argv[1], "e") || !strcmp(argv[1], "d"))) {
         // x3's option parser (final/x3/archon.c:101-110)
-        const char *sp = argv[2] + 2;
+        const char *sp = av[2] + 2;
         unsigned fsize = 0;
         for (; sp[0] >= '0' && sp[0] <= '9'; sp++) fsize = fsize * 10 + (unsigned)(sp[0] - '0');
         if (sp[0] == 'm') fsize <<= 20;
         else if (sp[0] == 'k') fsize <<= 10;
         if (fsize < 8 || fsize > 1u << 28) fsize = 1u << 22;
-        FILE *fi = fopen(argv[3], "rb");
+        FILE *fi = fopen(av[3], "rb");
         if (!fi) return -2;
-        FILE *fo = fopen(argv[4], "wb");
+        FILE *fo = fopen(av[4], "wb");
         if (!fo) { fclose(fi); return -3; }
         int ndev = archon_hip_device_count();
         if (const char *e = getenv("ARCHON_DEVICES")) { const int want = atoi(e); if (want > 0 && want < ndev) ndev = want; }
         const double t0c = now_sec();
-        const int rc = argv[1][0] == 'e' ? archon_container_encode(fi, fo, fsize, ndev) : archon_container_decode(fi, fo, ndev, &fsize);
+        const int rc = argv[1][0] == 'e' ? archon_container_encode(fi, fo, fsize, ndev, post ? 1 : 0) : archon_container_decode(fi, fo, ndev, &fsize);
         fclose(fi);
         fclose(fo);
         if (rc) {

@@ -41,6 +41,14 @@ uint32_t  archon_base_id(const archon_t *a);
 uint32_t  archon_length(const archon_t *a);
 void      archon_set_device(archon_t *a, int dev);     /* default 0 (or $ARCHON_DEVICE) */
 
+/* ---- optional post-BWT stage of the container CLI (`archon e -m -b<size>`): move-to-front, zero runs and an
+ * order-0 canonical Huffman code over one piece of BWT output.  PARITY UNPINNED: the reference
+ * has no such stage (README.md:2 only promises one); self-consistent, round-trip tested, host-side -- not part of
+ * the GPU hot path and not a fallback for it. */
+size_t    archon_post_bound(size_t n);                                          /* worst-case encoded bytes for n input bytes */
+size_t    archon_post_encode(const uint8_t *bwt, size_t n, uint8_t *out);       /* returns encoded bytes */
+int       archon_post_decode(const uint8_t *in, size_t in_bytes, uint8_t *bwt, size_t n);   /* 0 ok, -1 malformed */
+
 #ifdef __cplusplus
 }
 #endif

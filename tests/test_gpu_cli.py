@@ -218,3 +218,20 @@ def test_config5_mixed_corpus_full_size(archon, tmp_path):
         for chunk in iter(lambda: f.read(1 << 24), b""):
             h_out.update(chunk)
     assert h_out.hexdigest() == h_in.hexdigest()
+
+
+def test_container_with_post_stage(archon, tmp_path):
+    """`archon e -m -b<size>`: blocks through the MTF + entropy stage (no reference implementation --
+    PARITY UNPINNED, round trip only); `archon d -b` recognises the container by its signature."""
+    _build()
+    x = np.concatenate([S.gen_text(3 << 20), S.gen_motif(2 << 20), S.gen_dna(1 << 20), S.gen_random(300001)])
+    raw, enc, plain, dec = tmp_path / "in.raw", tmp_path / "out.rm", tmp_path / "out.ra", tmp_path / "back.raw"
+    x.tofile(raw)
+    r = subprocess.run([EXE, "e", "-m", "-b1m", str(raw), str(enc)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    r = subprocess.run([EXE, "e", "-b1m", str(raw), str(plain)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert np.fromfile(enc, np.uint8)[:2].tobytes() == b"RM" and os.path.getsize(enc) < os.path.getsize(plain)
+    r = subprocess.run([EXE, "d", "-b", str(enc), str(dec)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert (np.fromfile(dec, np.uint8) == x).all()
