@@ -902,6 +902,84 @@ int archon_hip_sa_to_bwt(const uint8_t *x, uint32_t n, const uint32_t *sa, uint8
     return ARCHON_OK;
 }
 
+static int lms_select_run(Ctx *c, hipStream_t s, const uint8_t *d_x, uint32_t n, uint32_t *d_count, uint32_t *d_items, uint32_t *n1_out)
+{
+    ARCHON_TRY(ctx_ensure_arena(c, forward_arena_bytes(n)));
+    c->arena_reset();
+    c->launches = 0;
+    uint32_t *v = c->alloc<uint32_t>(n), *flag = c->alloc<uint32_t>(n), *dst = c->alloc<uint32_t>(n);
+    uint64_t *kA = c->alloc<uint64_t>((size_t)n / 2 + 8), *kB = c->alloc<uint64_t>((size_t)n / 2 + 8);
+    uint32_t *vA = c->alloc<uint32_t>((size_t)n / 2 + 8), *vB = c->alloc<uint32_t>((size_t)n / 2 + 8);
+    uint32_t *scan_tmp = c->alloc<uint32_t>(scan_temp_words(n));
+    rs::Scratch sc;
+    sc.d_status = c->alloc<uint32_t>(rs::status_words(n));
+    sc.d_ghist = c->alloc<uint32_t>(8 * 256);
+    sc.d_gstart = c->alloc<uint32_t>(8 * 256);
+    uint32_t *small = c->alloc<uint32_t>(1024);
+    if (!small) { set_error("arena exhausted"); return ARCHON_E_NOMEM; }
+    sc.d_ticket = small + 601; sc.d_err = small + 602; sc.h_mail = c->h_mail;
+    ARCHON_HIP_TRY(hipMemsetAsync(small, 0, 1024 * sizeof(uint32_t), s));
+    const uint32_t g256 = div_up(n, 256);
+    hipLaunchKernelGGL(fwd::k_lms_pairs, dim3(g256), dim3(256), 0, s, d_x, n, v);
+    ARCHON_TRY(launch_scan<1>(s, v, v, n, scan_tmp, nullptr));
+    hipLaunchKernelGGL(fwd::k_lms_flag, dim3(g256), dim3(256), 0, s, d_x, n, v, flag);
+    ARCHON_TRY(launch_scan<0>(s, flag, dst, n, scan_tmp, small + 600));
+    ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, small + 600, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t n1 = c->h_mail[0];
+    *n1_out = n1;
+    ARCHON_HIP_TRY(hipMemsetAsync(d_count, 0, 256 * sizeof(uint32_t), s));
+    if (n1 == 1) {
+        hipLaunchKernelGGL(fwd::k_lms_compact, dim3(g256), dim3(256), 0, s, d_x, n, flag, dst, kA, vA);
+        hipLaunchKernelGGL(fwd::k_lms_single, dim3(1), dim3(1), 0, s, kA, vA, d_count, d_items);
+    } else if (n1) {
+        hipLaunchKernelGGL(fwd::k_lms_compact, dim3(g256), dim3(256), 0, s, d_x, n, flag, dst, kA, vA);
+        bool in_b = false;
+        uint32_t passes = 0;
+        ARCHON_TRY(rs::sort_pairs(s, sc, kA, vA, kB, vB, n1, 0x01u, &in_b, &passes, &c->launches));
+        // (sort_pairs has left the digit histogram of byte 0 = the per-bucket counts in d_ghist[0..255])
+        ARCHON_HIP_TRY(hipMemcpyAsync(d_count, sc.d_ghist, 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_scan257, dim3(1), dim3(64), 0, s, d_count, small);
+        hipLaunchKernelGGL(fwd::k_lms_place, dim3(div_up(n1, 256)), dim3(256), 0, s, in_b ? kB : kA, in_b ? vB : vA, n1, small, d_items);
+        ARCHON_HIP_TRY(hipGetLastError());
+    }
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    return ARCHON_OK;
+}
+
+int archon_hip_lms_select_dev(const uint8_t *d_x, uint32_t n, uint32_t *d_count256, uint32_t *d_items, uint32_t *n1, int dev, void *stream)
+{
+    if (!d_x || !d_count256 || !d_items || !n1) { set_error("null pointer"); return ARCHON_E_ARG; }
+    ARCHON_TRY(check_n(n));
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+    return lms_select_run(c, s, d_x, n, d_count256, d_items, n1);
+}
+
+int archon_hip_lms_select(const uint8_t *x, uint32_t n, uint32_t count[256], uint32_t *items, uint32_t *n1, int dev)
+{
+    if (!x || !count || !items || !n1) { set_error("null pointer"); return ARCHON_E_ARG; }
+    ARCHON_TRY(check_n(n));
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = c->own_stream;
+    uint8_t *d_x = nullptr;
+    uint32_t *d_items = nullptr;
+    ARCHON_TRY(ctx_io(c, 0, (size_t)n + 64, (void **)&d_x));
+    ARCHON_TRY(ctx_io(c, 2, ((size_t)n / 2 + 8) * 4, (void **)&d_items));
+    ARCHON_HIP_TRY(hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s));
+    ARCHON_TRY(lms_select_run(c, s, d_x, n, c->d_mail + 1024, d_items, n1));
+    ARCHON_HIP_TRY(hipMemcpyAsync(count, c->d_mail + 1024, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (*n1) ARCHON_HIP_TRY(hipMemcpyAsync(items, d_items, (size_t)*n1 * 4, hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    return ARCHON_OK;
+}
+
 int archon_hip_radix_scatter_dev(const uint8_t *d_src, size_t n, uint8_t *d_dst, int dev, void *stream)
 {
     if (!d_src || !d_dst) { set_error("null pointer"); return ARCHON_E_ARG; }

@@ -24,6 +24,7 @@ SYMBOLS = [
     "archon_hip_forward_keep", "archon_hip_read_bwt", "archon_hip_host_alloc", "archon_hip_host_free",
     "archon_hip_forward_dev", "archon_hip_inverse_dev", "archon_hip_hist256_dev",
     "archon_hip_validate_dev", "archon_hip_radix_scatter_dev", "archon_hip_sa_to_bwt", "archon_hip_sa_to_bwt_dev",
+    "archon_hip_lms_select", "archon_hip_lms_select_dev",
     "archon_hip_reserve", "archon_hip_release", "archon_hip_get_stats",
 ]
 
@@ -69,6 +70,8 @@ def load():
         "archon_hip_sa_to_bwt": [vp, u32, vp, vp, vp, i32],
         "archon_hip_sa_to_bwt_dev": [vp, u32, vp, vp, vp, i32, vp],
         "archon_hip_radix_scatter": [vp, sz, vp, i32],
+        "archon_hip_lms_select": [vp, u32, vp, vp, vp, i32],
+        "archon_hip_lms_select_dev": [vp, u32, vp, vp, vp, i32, vp],
         "archon_hip_forward_dev": [vp, u32, vp, vp, vp, i32, vp],
         "archon_hip_inverse_dev": [vp, u32, u32, vp, i32, vp],
         "archon_hip_hist256_dev": [vp, sz, vp, i32, vp],
@@ -150,6 +153,16 @@ def sa_to_bwt(x, sa, dev=0):
     base = ctypes.c_uint32(0)
     _check(lib().archon_hip_sa_to_bwt(_p(x), x.size, _p(sa), _p(bwt), ctypes.byref(base), dev))
     return bwt, int(base.value)
+
+
+def lms_select(x, dev=0):
+    """(count[256], items) of a7's findLMS (archon.cpp:160-172): the subset the reference sorts directly"""
+    x = np.ascontiguousarray(x, dtype=np.uint8)
+    count = np.zeros(256, np.uint32)
+    items = np.zeros(x.size // 2 + 8, np.uint32)
+    n1 = ctypes.c_uint32(0)
+    _check(lib().archon_hip_lms_select(_p(x), x.size, _p(count), _p(items), ctypes.cast(ctypes.byref(n1), ctypes.c_void_p), dev))
+    return count, items[:n1.value]
 
 
 def radix_scatter(src, dev=0):

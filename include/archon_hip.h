@@ -12,6 +12,7 @@
  *   archon_hip_validate     Archon::validate (862-874)
  *   archon_hip_sa_to_bwt    the gather loop of Archon::enWrite alone (887-900), for a caller's own SA
  *   archon_hip_radix_scatter  the counting-sort scatter of tool/radix_dir/radix.c:40-44
+ *   archon_hip_lms_select   Constructor::findLMS (160-172): the subset a7 sorts directly (a4 IT-2: bwt/a4/src/archon.c:163-169)
  *
  * Ordering convention ("a7 order"): item s in 1..N names the
  * reversed prefix x[s-1],x[s-2],...,x[0],INF with INF > 255; sa[0..N) lists the
@@ -87,6 +88,13 @@ int archon_hip_validate(const uint8_t *x, uint32_t n, const uint32_t *sa, int de
  * outside 1..n or not exactly one n. */
 int archon_hip_sa_to_bwt(const uint8_t *x, uint32_t n, const uint32_t *sa, uint8_t *bwt, uint32_t *base_id, int dev);
 
+/* The subset the reference sorts directly: a7's LMS items, Constructor::findLMS (archon.cpp:160-172;
+ * a4's IT-2 rule, bwt/a4/src/archon.c:163-169, is the same step in a4's convention).  count[c] = LMS items whose first
+ * key byte x[i-1] is c; items[] = the buckets' tails one after the other as a7 fills them (P[--RE[c]] = i: ascending
+ * slots hold decreasing items); *n1 = their number (<= n/2: items must hold n/2 + 8 words).  The GPU sorter itself
+ * sorts all N items -- this is the bucket-setup step as an operator of its own. */
+int archon_hip_lms_select(const uint8_t *x, uint32_t n, uint32_t count[256], uint32_t *items, uint32_t *n1, int dev);
+
 /* dst = src stably sorted by byte value (tool/radix_dir scatter), host pointers. */
 int archon_hip_radix_scatter(const uint8_t *src, size_t n, uint8_t *dst, int dev);
 
@@ -105,6 +113,8 @@ int archon_hip_validate_dev(const uint8_t *d_x, uint32_t n, const uint32_t *d_sa
 int archon_hip_sa_to_bwt_dev(const uint8_t *d_x, uint32_t n, const uint32_t *d_sa, uint8_t *d_bwt, uint32_t *d_base_id,
                              int dev, void *stream);
 int archon_hip_radix_scatter_dev(const uint8_t *d_src, size_t n, uint8_t *d_dst, int dev, void *stream);
+/* d_items: n/2 + 8 words; *n1 is a HOST pointer (the count is needed on the host to size the launches) */
+int archon_hip_lms_select_dev(const uint8_t *d_x, uint32_t n, uint32_t *d_count256, uint32_t *d_items, uint32_t *n1, int dev, void *stream);
 
 /* ---- workspace / lifetime ---------------------------------------------------- */
 

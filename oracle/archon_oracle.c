@@ -351,6 +351,33 @@ void oracle_radix_scatter(const uint8_t *src, size_t n, uint8_t *dst)
         dst[R[src[i]]++] = src[i];
 }
 
+/* A3: the subset a7 sorts directly -- Constructor::findLMS, bwt/a7/src/archon.cpp:160-172 (a4's IT-2 rule,
+ * bwt/a4/src/archon.c:163-169, and a6's IT-1 filter, bwt/a6/src/bwt.c:391-399, pick their subsets the same way in
+ * their own conventions).  The scan alternates between a falling phase (skip while x[i-1] >= x[i]) and a rising
+ * phase (skip while x[i-1] <= x[i]); the item at which a falling phase ends is an LMS item and is placed at the END of
+ * the bucket of its first key byte x[i-1], filling that bucket's tail downwards (P[--RE[x[i-1]]] = i).
+ * Output: count[c] = LMS items in bucket c; items[] = the buckets' tails one after the other, each in ascending slot
+ * order (= decreasing item).  Returns n1, the number of LMS items. */
+uint32_t oracle_lms_select(const uint8_t *x, uint32_t n, uint32_t count[256], uint32_t *items)
+{
+    uint32_t n1 = 0;
+    memset(count, 0, 256 * sizeof(uint32_t));
+    for (int pass = 0; pass < 2; ++pass) {          /* pass 0 counts, pass 1 places */
+        uint32_t end[256], acc = 0;
+        for (int c = 0; c < 256; ++c) { acc += count[c]; end[c] = acc; }
+        uint32_t i = 0;
+        for (;;) {
+            int done = 0;
+            do { if (++i >= n) { done = 1; break; } } while (x[i - 1] >= x[i]);      /* archon.cpp:164-167 */
+            if (done) break;
+            if (pass == 0) { ++count[x[i - 1]]; ++n1; }                              /* archon.cpp:168 ++n1 */
+            else items[--end[x[i - 1]]] = i;                                         /* archon.cpp:169 */
+            while (++i < n && x[i - 1] <= x[i]) {}                                   /* archon.cpp:170 */
+        }
+    }
+    return n1;
+}
+
 double oracle_clock_seconds(void)
 {
     return (double)clock() / CLOCKS_PER_SEC;

@@ -76,6 +76,8 @@ int oracle_inverse(const uint8_t *bwt, uint32_t n, uint32_t base_id, uint8_t *ou
 void oracle_radix_scatter(const uint8_t *src, size_t n, uint8_t *dst);
 
 /* Seconds of process CPU time, clock() as in bwt/a7/src/main.cpp:39-41. */
+/* A3: a7 findLMS (archon.cpp:160-172): per-bucket counts and the LMS items as a7 places them; returns n1 */
+uint32_t oracle_lms_select(const uint8_t *x, uint32_t n, uint32_t count[256], uint32_t *items);
 double oracle_clock_seconds(void);
 
 #ifdef __cplusplus

@@ -48,6 +48,8 @@ class Oracle:
         L.oracle_inverse.restype = ctypes.c_int
         L.oracle_radix_scatter.argtypes = [vp, sz, vp]
         L.oracle_radix_scatter.restype = None
+        L.oracle_lms_select.argtypes = [vp, u32, vp, vp]
+        L.oracle_lms_select.restype = u32
         L.oracle_clock_seconds.restype = ctypes.c_double
         self.L = L
 
@@ -105,6 +107,13 @@ class Oracle:
         out = np.empty(bwt.size, np.uint8)
         rc = self.L.oracle_inverse(_p(bwt), bwt.size, base, _p(out))
         return rc, out
+
+    def lms_select(self, x):
+        x = self._x(x)
+        count = np.zeros(256, np.uint32)
+        items = np.zeros(max(1, x.size), np.uint32)
+        n1 = self.L.oracle_lms_select(_p(x), x.size, _p(count), _p(items))
+        return count, items[:n1]
 
     def radix_scatter(self, src):
         src = self._x(src)

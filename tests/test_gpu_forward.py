@@ -373,3 +373,18 @@ def test_many_pass_ranges(archon, oracle, monkeypatch, ranges):
     sa, bwt, base = archon.forward(x)
     assert archon.stats()["path"] == 1 and archon.validate(x, sa)
     assert (archon.inverse(bwt, base) == x).all()
+
+
+def test_lms_select(archon, oracle):
+    """SURVEY A3: the subset a7 sorts directly (Constructor::findLMS, archon.cpp:160-172) as a GPU operator -- per-bucket
+    counts and the items in a7's placement order, against the oracle's restatement of the serial scan."""
+    rng = np.random.default_rng(21)
+    cases = [S.gen_shape(sh, n) for sh in ("random", "dna", "text", "a", "ab", "motif") for n in (1, 2, 3, 1000, 65537, 1 << 20)]
+    cases += [rng.integers(0, 3, 100001).astype(np.uint8), np.arange(256, dtype=np.uint8).repeat(5), np.arange(255, -1, -1, dtype=np.uint8).repeat(7)]
+    for x in cases:
+        count, items = archon.lms_select(x)
+        c0, i0 = oracle.lms_select(x)
+        assert (count == c0).all() and items.size == i0.size and (items == i0).all(), (x.size, x[:8])
+    x = S.gen_random(1 << 22)
+    _, items = archon.lms_select(x)
+    assert abs(items.size / x.size - 1 / 3) < 0.01          # SURVEY 8 A3: LMS density 0.33 on random bytes
