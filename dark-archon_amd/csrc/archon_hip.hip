@@ -129,6 +129,7 @@ static size_t forward_arena_bytes(uint32_t n)
     add(sizeof(bs::Prep));
     add(sizeof(uint2) * kTieListCap);
     add(sizeof(uint4) * (size_t)bs::kMaxRanges * bs::kTrashWords);
+    add(4 * (size_t)bs::kMaxRanges * 32768u);     // partial two-byte counts
     add(4 * 1024);                            // counts, starts, ticket, err, base, totals, TieCtl
     return b + 4096;
 }
@@ -142,6 +143,7 @@ struct FwdBuf {
     uint32_t *scan_tmp, *hist16, *small;
     bs::Prep *prep;
     uint2 *tie_list;
+    uint32_t *h16part;         // packed partial two-byte counts, one 128 KiB table per workgroup of k_hist16
     uint4 *trash;              // write-only trash lines of the pass workgroups (passes.hiph, emit_rec)
     rs::Scratch sc;
 };
@@ -329,6 +331,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     B.prep = c->alloc<bs::Prep>(1);                             // }  open Prep)
     B.tie_list = c->alloc<uint2>(kTieListCap);
     B.trash = c->alloc<uint4>((size_t)bs::kMaxRanges * bs::kTrashWords);
+    B.h16part = c->alloc<uint32_t>((size_t)bs::kMaxRanges * 32768u);
     B.small = c->alloc<uint32_t>(1024);
     if (!B.small) {
         set_error("arena exhausted");
@@ -395,16 +398,19 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         // the count runs with at most 256 workgroups per half: with more pass ranges each workgroup covers several of
         // them and reads the column sums off between two (more workgroups would only flush their 32 768 bins more often)
         const uint32_t sub = (R > 256u && R % 256u == 0u) ? R / 256u : 1u;
-        const dim3 grid(R / sub, 2), block(bs::kH16Block);
-        if (Q == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<1>), grid, block, 0, s, src, n, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
-        else if (Q == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<2>), grid, block, 0, s, src, n, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
-        else if (Q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<4>), grid, block, 0, s, src, n, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
+        const uint32_t nparts = div_up(R, sub);
+        const dim3 grid(nparts), block(bs::kH16Block);
+        // B.hist16 (zeroed above) first serves as the spill table of the count, then receives the totals (k_rows_total)
+        if (Q == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<1>), grid, block, 0, s, src, n, B.h16part, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
+        else if (Q == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<2>), grid, block, 0, s, src, n, B.h16part, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
+        else if (Q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<4>), grid, block, 0, s, src, n, B.h16part, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.h16part, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
+        hipLaunchKernelGGL(bs::k_hist16_sum, dim3(32, 8), dim3(256), 0, s, B.hist16, B.h16part, nparts);
         hipLaunchKernelGGL(bs::k_rows_total, dim3(256), dim3(256), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
         hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep, force_stream ? 1u : 0u, allow_aligned, d_ctl, (uint32_t)kTieListCap);
         hipLaunchKernelGGL(bs::k_col_prefix, dim3(256), dim3(1024), 0, s, rhist, R, &B.prep->skip);
         ARCHON_HIP_TRY(hipGetLastError());
-        c->launches += 4;
+        c->launches += 5;
         e1 = tm.mark();
         return ARCHON_OK;
     };

@@ -388,3 +388,20 @@ def test_lms_select(archon, oracle):
     x = S.gen_random(1 << 22)
     _, items = archon.lms_select(x)
     assert abs(items.size / x.size - 1 / 3) < 0.01          # LMS density 0.33 on random bytes
+
+
+def test_two_byte_count_hot_bins(archon, oracle):
+    """k_hist16 keeps 16-bit LDS counters that are cut back (and booked in a spill table) whenever they cross a multiple of
+    16 384: blocks whose two-byte bins hold far more than 65 535 items per workgroup must still be counted exactly --
+    five symbols (the low-entropy probe lets them through) with one of them 97 % of the block, and a skewed 30-symbol text."""
+    rng = np.random.default_rng(8)
+    n = 3 << 20
+    x = rng.choice(np.array([3, 50, 51, 52, 250], np.uint8), size=n, p=[0.97, 0.01, 0.01, 0.005, 0.005])
+    sa, bwt, base = archon.forward(x)
+    P, B, b0 = oracle.forward(x)
+    assert (sa == P).all() and (bwt == B).all() and base == b0
+    p = 0.5 ** np.arange(1, 31); p /= p.sum()
+    y = rng.choice(np.arange(60, 90, dtype=np.uint8), size=n, p=p)
+    sa, bwt, base = archon.forward(y)
+    P, B, b0 = oracle.forward(y)
+    assert (sa == P).all() and (bwt == B).all() and base == b0
