@@ -433,13 +433,13 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         constexpr int PB = bs::kPassBlock, PI = bs::kPassIPT;
         iA0 = ps.mark();
         if (Q == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 2>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, key_text, d_skip, B.trash);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 2>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, key_text, d_skip, B.trash, &d_ctl->base_bucket);
         else if (Q == 4)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 4>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, key_text, d_skip, B.trash);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 4>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, key_text, d_skip, B.trash, &d_ctl->base_bucket);
         else if (Q == 8)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 8>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, key_text, d_skip, B.trash);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 8>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, key_text, d_skip, B.trash, &d_ctl->base_bucket);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 1>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, d_x, d_skip, B.trash);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 1>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, d_x, d_skip, B.trash, &d_ctl->base_bucket);
         iA1 = ps.mark();
         // pass B walks the same tile grid in the same ranges; in bucket mode (Prep::aligned) workgroup c takes bucket c
         const uint32_t gridB = (allow_aligned && R < 256u) ? 256u : R;      // bucket mode needs 256; surplus workgroups return at once
