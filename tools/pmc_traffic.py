@@ -1,0 +1,38 @@
+"""Build profiles/pmc_traffic.json from the rocprofv3 --pmc passes tools/evidence.sh collects.
+
+usage: tools/pmc_traffic.py <pmc dir (gpurun_out/<tag>/pmc)> <source label> [n] [shape]
+
+Per kernel of the streaming path: mean FETCH_SIZE and WRITE_SIZE per dispatch (KiB, separate passes) ->
+HBM bytes per launch = 2 x FETCH_SIZE (gfx950 tallies 128-byte read requests at 64 bytes, MI355X_MICROARCH.md
+HBM section) + WRITE_SIZE.  bench.py reads the file for roofline.traffic."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+root, source = sys.argv[1], sys.argv[2]
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 268435456
+shape = sys.argv[4] if len(sys.argv) > 4 else "random"
+ALG = {"bs::k_pass_text": 5, "bs::k_pass_rec": 9, "bs::k_local_sort": 13, "bs::k_hist16": 1}
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
+for cc in glob.glob(root + "/*/*/*_counter_collection.csv"):
+    for r in csv.DictReader(open(cc)):
+        name = r["Kernel_Name"].split("(")[0].split("<")[0].replace("archon::", "").replace("void ", "").strip()
+        if name in ALG and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {"_comment": "HBM traffic per launch of the streaming kernels, MI355X, rocprofv3 separate --pmc passes (tools/pmc.sh via "
+                   "tools/evidence.sh): 2 x FETCH_SIZE (gfx950 under-count, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes. "
+                   "Source: " + source}
+ent = {}
+for name, c in vals.items():
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        continue
+    f = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
+    w = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+    ent[name] = {"fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024),
+                 "algorithmic_bytes_per_launch": ALG[name] * n, "source": source}
+out["path1_%s_%d" % (shape, n)] = ent
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(ent, indent=1))
