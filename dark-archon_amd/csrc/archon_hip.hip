@@ -8,6 +8,7 @@
 #include "inverse.hiph"
 
 #include <stdarg.h>
+#include <chrono>
 #include <stdlib.h>
 #include <vector>
 
@@ -152,9 +153,23 @@ struct FwdBuf {
 // first-stage order, v[i] = i at the first row of every group of equal h-byte keys and 0
 // elsewhere.  Runs scan -> scatter_rank -> doubling rounds -> sa_to_bwt.
 static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, uint32_t n, uint32_t *sa, uint32_t h0,
-                         uint8_t *d_bwt, uint32_t *d_base, archon_hip_stats &st)
+                         uint8_t *d_bwt, uint32_t *d_base, archon_hip_stats &st, uint32_t p_hint = 0)
 {
     const uint32_t g256 = div_up(n, 256);
+#ifdef ARCHON_EXPERIMENTS
+    const bool tracing = getenv("ARCHON_TRACE_ROUNDS") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto trace = [&](const char *what) {
+        if (!tracing) return;
+        (void)hipStreamSynchronize(s);
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "  general_stage: %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+        t_last = t;
+    };
+#else
+    auto trace = [](const char *) {};
+#endif
+    trace("enter");
     ARCHON_TRY(launch_scan<1>(s, B.v, B.v, n, B.scan_tmp, nullptr));
     hipLaunchKernelGGL(fwd::k_keep_flags, dim3(g256), dim3(256), 0, s, B.v, n, B.keep);
     uint32_t *d_total = B.small + 600;
@@ -164,38 +179,57 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     c->launches += 7;
     uint32_t m = c->h_mail[0];
     st.unresolved_initial = m;
+    trace("scan + keep + scan");
     // long-repeat defence: when much of the block is tied and one neighbour gap dominates the tied groups,
     // settle the periodic runs directly (forward.hiph, k_chain_*) before any doubling round
     if (m >= n / 16 && !getenv("ARCHON_NO_CHAINS")) {
-        uint32_t *tab = B.upos[0];                      // 2 * kGapSlots words; upos is idle until the compaction
-        ARCHON_HIP_TRY(hipMemsetAsync(tab, 0, 2 * fwd::kGapSlots * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(fwd::k_gap_sample, dim3(div_up(div_up(n, fwd::kGapStride), 256)), dim3(256), 0, s, sa, B.v, n, tab);
-        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, tab, 2 * fwd::kGapSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
-        c->launches += 1;
-        uint64_t total = 0;
-        uint32_t best = 0;
-        for (uint32_t i = 0; i < fwd::kGapSlots; ++i) {
-            total += c->h_mail[i];
-            if (c->h_mail[i] > c->h_mail[best]) best = i;
+        uint32_t p = p_hint;
+        bool dominant = p_hint != 0;        // the driver's period probe already named the period (and the groups may be unordered)
+        if (!dominant) {
+            uint32_t *tab = B.upos[0];                      // 2 * kGapSlots words; upos is idle until the compaction
+            ARCHON_HIP_TRY(hipMemsetAsync(tab, 0, 2 * fwd::kGapSlots * sizeof(uint32_t), s));
+            hipLaunchKernelGGL(fwd::k_gap_sample, dim3(div_up(div_up(n, fwd::kGapStride), 256)), dim3(256), 0, s, sa, B.v, n, tab);
+            ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, tab, 2 * fwd::kGapSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            ARCHON_HIP_TRY(hipStreamSynchronize(s));
+            c->launches += 1;
+            uint64_t total = 0;
+            uint32_t best = 0;
+            for (uint32_t i = 0; i < fwd::kGapSlots; ++i) {
+                total += c->h_mail[i];
+                if (c->h_mail[i] > c->h_mail[best]) best = i;
+            }
+            p = c->h_mail[fwd::kGapSlots + best];
+            dominant = (uint64_t)c->h_mail[best] * 4 >= total;
         }
-        const uint32_t p = c->h_mail[fwd::kGapSlots + best];
-        if (p >= 1 && p < n && (uint64_t)c->h_mail[best] * 4 >= total) {
+        if (p >= 1 && p < n && dominant) {
             uint32_t *brk = B.rank, *ginfo = B.dst, *gend = B.keep, *settled = B.small + 601;
+            uint32_t *gmin = B.ug[0], *gmax = B.ug[1];          // idle until the compaction
             hipLaunchKernelGGL(fwd::k_period_breaks, dim3(g256), dim3(256), 0, s, d_x, n, p, brk);
             ARCHON_TRY(launch_scan<1>(s, brk, brk, n, B.scan_tmp, nullptr));
-            ARCHON_HIP_TRY(hipMemsetAsync(ginfo, 0, (size_t)n * sizeof(uint32_t), s));
+            hipLaunchKernelGGL(fwd::k_chain_init, dim3(g256), dim3(256), 0, s, B.v, n, gmin, gmax, ginfo);
             ARCHON_HIP_TRY(hipMemsetAsync(settled, 0, sizeof(uint32_t), s));
-            hipLaunchKernelGGL(fwd::k_chain_probe, dim3(g256), dim3(256), 0, s, d_x, sa, B.v, brk, n, p, ginfo, gend);
-            hipLaunchKernelGGL(fwd::k_chain_apply, dim3(g256), dim3(256), 0, s, sa, B.v, ginfo, gend, n, d_bwt, d_base, settled);
-            // the tied set again, without the settled groups
-            hipLaunchKernelGGL(fwd::k_keep_flags, dim3(g256), dim3(256), 0, s, B.v, n, B.keep);
-            ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, n, B.scan_tmp, d_total));
-            ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            trace("breaks + scan + memsets");
+            hipLaunchKernelGGL(fwd::k_chain_minmax, dim3(div_up(n, fwd::kChainRows)), dim3(256), 0, s, sa, B.v, n, gmin, gmax);
+            trace("chain_minmax");
+            hipLaunchKernelGGL(fwd::k_chain_probe, dim3(g256), dim3(256), 0, s, d_x, sa, B.v, brk, n, p, gmin, gmax, ginfo, gend);
+            trace("chain_probe");
+            hipLaunchKernelGGL(fwd::k_chain_apply, dim3(g256), dim3(256), 0, s, sa, B.v, ginfo, gend, gmin, gmax, brk, d_x, n, p, d_bwt, d_base, settled);
+            trace("chain_apply");
             ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 1, settled, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             ARCHON_HIP_TRY(hipStreamSynchronize(s));
-            c->launches += 10;
-            m = c->h_mail[0];
+            c->launches += 8;
+            if (c->h_mail[1] >= m) {
+                m = 0;                          // every tied row was settled: nothing to count or compact
+            } else {
+                // the tied set again, without the settled groups
+                hipLaunchKernelGGL(fwd::k_keep_flags, dim3(g256), dim3(256), 0, s, B.v, n, B.keep);
+                ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, n, B.scan_tmp, d_total));
+                ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                ARCHON_HIP_TRY(hipStreamSynchronize(s));
+                c->launches += 3;
+                m = c->h_mail[0];
+            }
+            trace("keep + scan again");
             st.period = p;
             st.chain_items = c->h_mail[1];
         }
@@ -214,32 +248,89 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     // Text rounds: while few items are tied, key them on the next four bytes of the text instead of on ranks -- no
     // inverse suffix array yet (its 4N-byte scatter costs more than a whole round on a small working set).  They stop
     // as soon as a round fails to halve the working set (long repeats: doubling is what resolves those).
+    // One round's ordering: every group of the working set sorted on its items' 32-bit keys (mode 0: rank[s-h], mode 1:
+    // the next four text bytes); on return vR[j] = the items in their new order and B.vw[j] = the row where the new
+    // group of entry j starts.  Short groups are sorted inside k_seg_round; entries of long ones go through the global
+    // radix sort -- alone if they are the minority, otherwise the whole working set does (the original route).
+    const bool seg_ok = !getenv("ARCHON_NO_SEG_ROUNDS");
+    uint32_t *d_nbig = B.small + 604;
+    auto round_sort = [&](int mode, uint32_t mm, uint32_t hh, int cu, uint32_t **vR_out) -> int {
+        const uint32_t gm = div_up(mm, 256);
+        if (seg_ok) {
+            ARCHON_HIP_TRY(hipMemsetAsync(d_nbig, 0, sizeof(uint32_t), s));
+            const uint32_t gs = div_up(mm, fwd::kSegTile);
+            if (mode == 0)
+                hipLaunchKernelGGL(fwd::k_round_keys<0>, dim3(gm), dim3(256), 0, s, B.uitem[cu], B.rank, d_x, hh, mm, B.dst);
+            else
+                hipLaunchKernelGGL(fwd::k_round_keys<1>, dim3(gm), dim3(256), 0, s, B.uitem[cu], B.rank, d_x, hh, mm, B.dst);
+            hipLaunchKernelGGL(fwd::k_seg_round, dim3(gs), dim3(256), 0, s, B.ug[cu], B.uitem[cu], B.dst, mm, kT, vT, B.vw, B.keep, d_nbig);
+            ARCHON_HIP_TRY(hipGetLastError());
+            ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_nbig, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            ARCHON_HIP_TRY(hipStreamSynchronize(s));
+            ++c->launches;
+            const uint32_t nbig = c->h_mail[0];
+            st.seg_big_items += nbig;
+            *vR_out = vT;
+            ++c->launches;
+            if (nbig == 0) return ARCHON_OK;
+            // the entries of long groups: compacted, sorted globally on (group, key), put back.  Buffers: the (group, key)
+            // pairs of k_seg_round are dead once gathered, so kT is the sort's second key buffer; the next working set's
+            // item array is idle until this round is compacted and lends the second value buffer.
+            ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, mm, B.scan_tmp, d_total));
+            hipLaunchKernelGGL(fwd::k_big_gather, dim3(gm), dim3(256), 0, s, B.keep, B.dst, kT, vT, mm, kS, vS);
+            bool b2 = false;
+            uint32_t passes = 0;
+            ARCHON_TRY(rs::sort_pairs(s, B.sc, kS, vS, kT, B.uitem[cu ^ 1], nbig, 0xFFu, &b2, &passes, &c->launches));
+            hipLaunchKernelGGL(fwd::k_big_scatter, dim3(gm), dim3(256), 0, s, B.keep, B.dst, b2 ? kT : kS, b2 ? B.uitem[cu ^ 1] : vS,
+                               B.upos[cu], mm, vT, B.vw);
+            ARCHON_TRY(launch_scan<1>(s, B.vw, B.vw, mm, B.scan_tmp, nullptr));
+            c->launches += 6;
+            return ARCHON_OK;
+        }
+        if (mode == 0)
+            hipLaunchKernelGGL(fwd::k_gather_rank, dim3(gm), dim3(256), 0, s, B.ug[cu], B.uitem[cu], B.rank, hh, mm, kT, vT);
+        else
+            hipLaunchKernelGGL(fwd::k_gather_text, dim3(gm), dim3(256), 0, s, B.ug[cu], B.uitem[cu], d_x, hh, mm, kT, vT);
+        ARCHON_HIP_TRY(hipGetLastError());
+        bool b2 = false;
+        uint32_t passes = 0;
+        ARCHON_TRY(rs::sort_pairs(s, B.sc, kT, vT, kS, vS, mm, 0xFFu, &b2, &passes, &c->launches));
+        hipLaunchKernelGGL(fwd::k_flag_round, dim3(gm), dim3(256), 0, s, b2 ? kS : kT, B.upos[cu], mm, B.vw);
+        ARCHON_TRY(launch_scan<1>(s, B.vw, B.vw, mm, B.scan_tmp, nullptr));
+        c->launches += 4;
+        *vR_out = b2 ? vS : vT;
+        return ARCHON_OK;
+    };
+    // the rest of a round: items and group starts back into the tables, survivors compacted into the next working set
+    auto round_finish = [&](bool text, uint32_t mm, int cu, uint32_t *vR, uint32_t *m2_out) -> int {
+        const uint32_t gm = div_up(mm, 256);
+        if (text)
+            hipLaunchKernelGGL(fwd::k_round_update_text, dim3(gm), dim3(256), 0, s, vR, B.upos[cu], B.vw, mm, sa, B.v, B.keep);
+        else
+            hipLaunchKernelGGL(fwd::k_round_update, dim3(gm), dim3(256), 0, s, vR, B.upos[cu], B.vw, mm, sa, B.rank, B.keep);
+        ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, mm, B.scan_tmp, d_total));
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        c->launches += 4;
+        *m2_out = c->h_mail[0];
+        if (*m2_out) {
+            hipLaunchKernelGGL(fwd::k_compact_round, dim3(gm), dim3(256), 0, s, B.keep, B.dst, B.upos[cu], B.vw, vR, mm,
+                               B.upos[cu ^ 1], B.ug[cu ^ 1], B.uitem[cu ^ 1]);
+            ARCHON_HIP_TRY(hipGetLastError());
+            ++c->launches;
+        }
+        return ARCHON_OK;
+    };
     const bool text_ok = !getenv("ARCHON_NO_TEXT_ROUNDS");
     while (m && text_ok && (uint64_t)m * 4 <= n && st.text_rounds < 4 && h < n) {
         st.unresolved_total += m;
         ++st.text_rounds;
-        const uint32_t gm = div_up(m, 256);
-        hipLaunchKernelGGL(fwd::k_gather_text, dim3(gm), dim3(256), 0, s, B.ug[cur], B.uitem[cur], d_x, h, m, kT, vT);
-        ARCHON_HIP_TRY(hipGetLastError());
-        bool b2 = false;
-        uint32_t passes = 0;
-        ARCHON_TRY(rs::sort_pairs(s, B.sc, kT, vT, kS, vS, m, 0xFFu, &b2, &passes, &c->launches));
-        uint64_t *kR = b2 ? kS : kT;
-        uint32_t *vR = b2 ? vS : vT;
-        hipLaunchKernelGGL(fwd::k_flag_round, dim3(gm), dim3(256), 0, s, kR, B.upos[cur], m, B.vw);
-        ARCHON_TRY(launch_scan<1>(s, B.vw, B.vw, m, B.scan_tmp, nullptr));
-        hipLaunchKernelGGL(fwd::k_round_update_text, dim3(gm), dim3(256), 0, s, vR, B.upos[cur], B.vw, m, sa, B.v, B.keep);
-        ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, m, B.scan_tmp, d_total));
-        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
-        c->launches += 9;
-        const uint32_t m2 = c->h_mail[0];
-        if (m2) {
-            hipLaunchKernelGGL(fwd::k_compact_round, dim3(gm), dim3(256), 0, s, B.keep, B.dst, B.upos[cur], B.vw, vR, m,
-                               B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1]);
-            ARCHON_HIP_TRY(hipGetLastError());
-            ++c->launches;
-        }
+        uint32_t *vR = nullptr, m2 = 0;
+        trace("before text round");
+        ARCHON_TRY(round_sort(1, m, h, cur, &vR));
+        trace("text round sort");
+        ARCHON_TRY(round_finish(true, m, cur, vR, &m2));
+        trace("text round finish");
         cur ^= 1;
         h += 4;
         const bool productive = (uint64_t)m2 * 2 <= m;
@@ -248,34 +339,34 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     }
     if (m) {
         // ranks are needed only now (4N random stores): every item, not just the tied ones
+        trace("before scatter_rank");
         hipLaunchKernelGGL(fwd::k_scatter_rank, dim3(g256), dim3(256), 0, s, sa, B.v, n, sa, B.rank, B.keep);
         ++c->launches;
+        trace("scatter_rank");
     }
     while (m) {
         st.unresolved_total += m;
         ++st.doubling_rounds;
-        const uint32_t gm = div_up(m, 256);
-        hipLaunchKernelGGL(fwd::k_gather_rank, dim3(gm), dim3(256), 0, s, B.ug[cur], B.uitem[cur], B.rank, h, m, kT, vT);
-        ARCHON_HIP_TRY(hipGetLastError());
-        bool b2 = false;
-        uint32_t passes = 0;
-        ARCHON_TRY(rs::sort_pairs(s, B.sc, kT, vT, kS, vS, m, 0xFFu, &b2, &passes, &c->launches));
-        uint64_t *kR = b2 ? kS : kT;
-        uint32_t *vR = b2 ? vS : vT;
-        hipLaunchKernelGGL(fwd::k_flag_round, dim3(gm), dim3(256), 0, s, kR, B.upos[cur], m, B.vw);
-        ARCHON_TRY(launch_scan<1>(s, B.vw, B.vw, m, B.scan_tmp, nullptr));
-        hipLaunchKernelGGL(fwd::k_round_update, dim3(gm), dim3(256), 0, s, vR, B.upos[cur], B.vw, m, sa, B.rank, B.keep);
-        ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, m, B.scan_tmp, d_total));
-        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        uint32_t *vR = nullptr, m2 = 0;
+#ifdef ARCHON_EXPERIMENTS
+        const uint64_t big0 = st.seg_big_items;
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
-        c->launches += 9;
-        const uint32_t m2 = c->h_mail[0];
-        if (m2) {
-            hipLaunchKernelGGL(fwd::k_compact_round, dim3(gm), dim3(256), 0, s, B.keep, B.dst, B.upos[cur], B.vw, vR, m,
-                               B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1]);
-            ARCHON_HIP_TRY(hipGetLastError());
-            ++c->launches;
+        const auto t0 = std::chrono::steady_clock::now();
+#endif
+        ARCHON_TRY(round_sort(0, m, h, cur, &vR));
+#ifdef ARCHON_EXPERIMENTS
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        const auto t1 = std::chrono::steady_clock::now();
+#endif
+        ARCHON_TRY(round_finish(false, m, cur, vR, &m2));
+#ifdef ARCHON_EXPERIMENTS
+        if (getenv("ARCHON_TRACE_ROUNDS")) {
+            ARCHON_HIP_TRY(hipStreamSynchronize(s));
+            const auto t2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "round h=%u m=%u big=%llu sort %.3f ms finish %.3f ms -> m2=%u\n", h, m, (unsigned long long)(st.seg_big_items - big0),
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(), m2);
         }
+#endif
         cur ^= 1;
         m = m2;
         if (h > n && m) {   // h >= n resolves everything; reaching here means an internal fault
@@ -285,6 +376,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         h = h > 0x40000000u ? 0x80000000u : h * 2;
     }
     // A7 for the rows the doubling rounds moved (every other row already holds its symbol)
+    trace("rounds done");
     if (m0) {
         hipLaunchKernelGGL(fwd::k_bwt_fix, dim3(div_up(m0, 256)), dim3(256), 0, s, d_x, sa, B.uinit, m0, n, d_bwt, d_base);
         ARCHON_HIP_TRY(hipGetLastError());
@@ -428,7 +520,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         return ARCHON_OK;
     };
     // ---- streaming first stage: two LSB passes + in-LDS bucket sorts; ends with the block's host round trip ----
-    auto streaming = [&](int Q, const uint8_t *key_text) -> int {
+    auto streaming = [&](int Q, const uint8_t *key_text, bool defer_big = false) -> int {
         // (the tie summary was initialised on the device by k_rows_scan, which also left the count summary in it)
         constexpr int PB = bs::kPassBlock, PI = bs::kPassIPT;
         iA0 = ps.mark();
@@ -438,6 +530,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 4>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, key_text, d_skip, B.trash, &d_ctl->base_bucket);
         else if (Q == 8)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 8>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, key_text, d_skip, B.trash, &d_ctl->base_bucket);
+        else if (defer_big)      // periodic block: a few digits per tile
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 1, true>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, d_x, d_skip, B.trash, &d_ctl->base_bucket);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 1>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, d_x, d_skip, B.trash, &d_ctl->base_bucket);
         iA1 = ps.mark();
@@ -446,12 +540,20 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         hipLaunchKernelGGL(bs::k_range_hist_text, dim3(R), dim3(bs::kRhBlock), 0, s, A_B1, n, tpr, rhist, 0u, kTileItems, d_skip);
         hipLaunchKernelGGL(bs::k_col_prefix, dim3(256), dim3(1024), 0, s, rhist, R, d_skip);          // (harmless in bucket mode: the table is not read)
         iB0 = ps.mark();
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<bs::kPassBBlock, bs::kPassBIPT>), dim3(gridB), dim3(bs::kPassBBlock), 0, s, A_R, A_B1, n, tpr, B_R,
-                           B.prep->startB, rhist, B.prep->startA, d_skip, B.prep->start16, B.trash);
+        if (defer_big)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<bs::kPassBBlock, bs::kPassBIPT, true>), dim3(gridB), dim3(bs::kPassBBlock), 0, s, A_R, A_B1, n, tpr, B_R,
+                               B.prep->startB, rhist, B.prep->startA, d_skip, B.prep->start16, B.trash);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<bs::kPassBBlock, bs::kPassBIPT>), dim3(gridB), dim3(bs::kPassBBlock), 0, s, A_R, A_B1, n, tpr, B_R,
+                               B.prep->startB, rhist, B.prep->startA, d_skip, B.prep->start16, B.trash);
         iB1 = ps.mark();
         e2 = tm.mark();
         hipLaunchKernelGGL(bs::k_local_sort, dim3(65536), dim3(bs::kLsBlock), 0, s, B_R, B.prep->start16, n, sa,
-                           d_bwt, d_ctl, B.tie_list, d_skip);
+                           d_bwt, d_ctl, B.tie_list, d_skip, defer_big ? 1u : 0u);
+        if (defer_big) {
+            hipLaunchKernelGGL(bs::k_unpack_big, dim3(div_up(n, bs::kUnpackChunk)), dim3(256), 0, s, B_R, B.prep->start16, n, sa, d_bwt, d_ctl, d_skip);
+            ++c->launches;
+        }
         e2b = tm.mark();
         hipLaunchKernelGGL(bs::k_resolve_ties, dim3(div_up(kTieListCap, 256)), dim3(256), 0, s, d_x, n, B.tie_list, d_ctl,
                            sa, d_bwt, 5u * (uint32_t)Q, 64u * (uint32_t)Q, d_skip);
@@ -509,6 +611,38 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             ARCHON_TRY(count16(1, d_x, false, false));
             ARCHON_TRY(streaming(1, d_x));
             path = ((uint64_t)big_items * 2 <= n) ? 1 : 0;
+        }
+    }
+    // A periodic block (aaa..., abab..., a motif repeated: BASELINE.json configs[2]) needs no deep first stage: the run
+    // shortcut of general_stage settles its chains whatever depth the first stage reached.  So it takes the streaming
+    // passes after all -- two key bytes, its oversized buckets handed on as groups tied at depth 2 (k_unpack_big) --
+    // or, with that route switched off, three key bytes of the 7-pass sort.
+    uint32_t key_bytes = fwd::kKeyBytes, period_hint = 0;
+    if (path == 0 && n >= (1u << 16) && !getenv("ARCHON_NO_PERIOD_PROBE")) {
+        uint32_t *pres = small + 610;
+        c->h_mail[0] = 0xFFFFFFFFu; c->h_mail[1] = 0;
+        ARCHON_HIP_TRY(hipMemcpyAsync(pres, c->h_mail, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(fwd::k_period_find, dim3(fwd::kPeriodSearch / 256), dim3(256), 0, s, d_x, n, pres);
+        hipLaunchKernelGGL(fwd::k_period_vote, dim3(fwd::kPeriodVotes / 256), dim3(256), 0, s, d_x, n, pres);
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, pres, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        c->launches += 2;
+        if (c->h_mail[0] != 0xFFFFFFFFu && c->h_mail[1] * 10 >= fwd::kPeriodVotes * 9) {
+            key_bytes = 3;
+            // ... provided every two-byte bucket is ONE run of the period: a bucket that joins two phases of the period (the same
+            // two bytes at two places of the motif) is no run, and sorting it out at depth 2 costs more than a third key
+            // byte.  The two-byte count tells: a single run holds n / p items.  (Periods 1 and 2 cannot collide.)
+            const uint32_t pp = c->h_mail[0];
+            const bool count_ok = forced < 0 && !h_ctl.suspect;
+            const bool single_runs = pp <= 2 || (count_ok && (uint64_t)h_ctl.max_bucket * 2 * pp <= (uint64_t)n * 3);
+            if (forced < 0 && single_runs && !getenv("ARCHON_NO_PERIOD_STREAM")) {
+                period_hint = pp;               // the streaming passes keep no order inside a bucket: no gap sampling there
+                ARCHON_TRY(count16(1, d_x, true));
+                ARCHON_TRY(streaming(1, d_x, true));
+                path = 1;
+                Q = 1;
+                st.alphabet_bits = 0;
+            }
         }
     }
     if (path == 0) {
@@ -574,20 +708,6 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         // ---- first stage for heavily skewed blocks: LSB passes on packed 7-byte keys ----
         // alphabet compaction: with <= 16 distinct bytes the key holds 56/bits symbols
         const bool packed = sigma <= 16 && !getenv("ARCHON_NO_PACK");
-        // A periodic block (aaa..., abab..., a motif repeated: BASELINE.json configs[2]) needs no deep first stage:
-        // three key bytes separate the phases of the period, the run shortcut of general_stage settles the chains.
-        uint32_t key_bytes = fwd::kKeyBytes;
-        if (n >= (1u << 16) && !getenv("ARCHON_NO_PERIOD_PROBE")) {
-            uint32_t *pres = small + 610;
-            c->h_mail[0] = 0xFFFFFFFFu; c->h_mail[1] = 0;
-            ARCHON_HIP_TRY(hipMemcpyAsync(pres, c->h_mail, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(fwd::k_period_find, dim3(fwd::kPeriodSearch / 256), dim3(256), 0, s, d_x, n, pres);
-            hipLaunchKernelGGL(fwd::k_period_vote, dim3(fwd::kPeriodVotes / 256), dim3(256), 0, s, d_x, n, pres);
-            ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, pres, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            ARCHON_HIP_TRY(hipStreamSynchronize(s));
-            c->launches += 2;
-            if (c->h_mail[0] != 0xFFFFFFFFu && c->h_mail[1] * 10 >= fwd::kPeriodVotes * 9) key_bytes = 3;
-        }
         if (packed) {
             h0 = 56 / bits;
             hipLaunchKernelGGL(fwd::k_init_keys_packed, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, d_lut, bits, h0,
@@ -613,7 +733,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     }
 
     if (need_general) {
-        ARCHON_TRY(general_stage(c, s, B, d_x, n, sa, h0, d_bwt, d_base, st));
+        ARCHON_TRY(general_stage(c, s, B, d_x, n, sa, h0, d_bwt, d_base, st, period_hint));
         e4 = tm.mark();
         ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, d_base, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }

@@ -42,7 +42,7 @@ class Stats(ctypes.Structure):
         ("path", ctypes.c_uint32), ("tie_groups", ctypes.c_uint32), ("tie_items", ctypes.c_uint32),
         ("ms_pass_text", ctypes.c_float), ("ms_pass_rec", ctypes.c_float),
         ("alphabet_bits", ctypes.c_uint32), ("period", ctypes.c_uint32),
-        ("chain_items", ctypes.c_uint32), ("text_rounds", ctypes.c_uint32),
+        ("chain_items", ctypes.c_uint32), ("text_rounds", ctypes.c_uint32), ("seg_big_items", ctypes.c_uint64),
     ]
 
     def asdict(self):

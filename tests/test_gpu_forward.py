@@ -232,11 +232,62 @@ def test_long_repeats(archon, oracle, name):
     assert (bwt == B).all() and base == b0
 
 
-def test_long_repeats_use_the_shortcut(archon):
+@pytest.mark.parametrize("route", ["streaming", "lsb"])
+def test_long_repeats_use_the_shortcut(archon, monkeypatch, route):
+    """periodic blocks: two streaming passes + the run shortcut (default), or three LSB passes + the shortcut"""
+    if route == "lsb":
+        monkeypatch.setenv("ARCHON_NO_PERIOD_STREAM", "1")
     x = np.tile(np.frombuffer(b"ab", np.uint8), 1 << 20)
     archon.forward(x)
     st = archon.stats()
     assert st["period"] == 2 and st["chain_items"] > x.size * 0.99 and st["doubling_rounds"] == 0
+    assert st["path"] == (1 if route == "streaming" else 0)
+
+
+@pytest.mark.parametrize("name", ["a", "ab", "motif1000", "motif_with_glitches", "three_runs", "nested"])
+def test_long_repeats_lsb_route(archon, oracle, name, monkeypatch):
+    """the same gauntlet with the periodic blocks kept on the 7-pass route (ordered groups, gap sampling)"""
+    monkeypatch.setenv("ARCHON_NO_PERIOD_STREAM", "1")
+    x = _repeat_cases()[name]
+    sa, bwt, base = archon.forward(x)
+    P, B, b0 = oracle.forward(x)
+    assert (sa == P).all() and (bwt == B).all() and base == b0
+
+
+def _seg_cases():
+    rng = np.random.default_rng(77)
+    r = lambda k, hi=256: rng.integers(0, hi, size=k, dtype=np.uint8)
+    R = r(200000)
+    words = [bytes(r(int(k), 26) + 97) for k in rng.integers(2, 9, size=300)]
+    prose = np.frombuffer(b" ".join(words[i] for i in rng.integers(0, 300, size=120000)), np.uint8)
+    runs = np.concatenate([np.concatenate([np.full(int(k), 32, np.uint8), r(40, 26) + 97]) for k in rng.integers(1, 400, size=2500)])
+    return {
+        "duplicated_block": np.concatenate([R, r(7), R, r(3), R[:150000]]),                 # pairs and triples, deep repeats
+        "prose": prose,                                                                     # skewed groups of every size
+        "prose_twice": np.concatenate([prose[:300000], prose[:300000]]),
+        "space_runs": runs,                                                                 # long groups next to short ones
+        "dups_and_runs": np.concatenate([R[:60000], runs[:200000], R[:60000], np.full(5000, 7, np.uint8), R[:999]]),
+    }
+
+
+@pytest.mark.parametrize("name", sorted(_seg_cases()))
+def test_segmented_rounds(archon, oracle, name, monkeypatch):
+    """Refinement rounds (text rounds and prefix doubling) with short groups sorted inside k_seg_round and long groups
+    through the global sort, in every mix: same order as the oracle, and the same as with the segmented sort off."""
+    x = _seg_cases()[name]
+    P, B, b0 = oracle.forward(x)
+    for env in ({}, {"ARCHON_FORCE_PATH": "0"}, {"ARCHON_NO_TEXT_ROUNDS": "1", "ARCHON_NO_CHAINS": "1"}, {"ARCHON_NO_SEG_ROUNDS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sa, bwt, base = archon.forward(x)
+        st = archon.stats()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert (sa == P).all(), (name, env)
+        assert (bwt == B).all() and base == b0
+        if "ARCHON_NO_SEG_ROUNDS" in env:
+            assert st["seg_big_items"] == 0
+    assert st["text_rounds"] + st["doubling_rounds"] > 0
 
 
 @pytest.mark.parametrize("sigma", [2, 3, 4, 5, 9, 16])
@@ -291,8 +342,9 @@ def test_max_block(archon, shape):
     base_t = torch.zeros(1, dtype=torch.int32, device="cuda")
     archon.forward_dev(x_t, sa_t, bwt_t, base_t)
     st = archon.stats()
-    # beyond ~300 MB the two-byte buckets of even a uniform block exceed the in-LDS sort (4608 items): 7-pass route
-    assert st["path"] == 0
+    # beyond ~300 MB the two-byte buckets of even a uniform block exceed the in-LDS sort (4608 items): 7-pass route;
+    # a periodic block takes the two streaming passes whatever its size (its buckets go on as groups tied at depth 2)
+    assert st["path"] == (0 if shape == "random" else 1)
     base = int(base_t.item())
     assert int(sa_t[base].item()) == n
     if shape == "a":      # a^N: the order is N, N-1, ..., 1
