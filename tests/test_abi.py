@@ -36,9 +36,19 @@ def test_host_library_exports_header():
         assert hasattr(lib, name), name
 
 
-def test_stats_struct_size():
+def test_stats_struct_size(tmp_path):
+    """the ctypes mirror of archon_hip_stats has the size and the field offsets the C header gives it"""
+    import subprocess
     import pyarchon
-    assert ctypes.sizeof(pyarchon.Stats) == 128   # sizeof(archon_hip_stats)
+    names = [k for k, _ in pyarchon.Stats._fields_ if not k.startswith("_")]
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "archon_hip.h"\nint main(void){printf("%zu", sizeof(archon_hip_stats));'
+                   + "".join('printf(" %%zu", offsetof(archon_hip_stats, %s));' % k for k in names) + "return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(t) for t in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got[0] == ctypes.sizeof(pyarchon.Stats)
+    assert got[1:] == [getattr(pyarchon.Stats, k).offset for k in names]
 
 
 def test_no_cpu_fallback():
