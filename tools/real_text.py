@@ -41,6 +41,6 @@ for rep in range(2):
 ok = pyarchon.validate(x, sa)
 back = pyarchon.inverse(bwt, base)
 si = pyarchon.stats()
-keys = ("path", "radix_passes", "doubling_rounds", "unresolved_initial", "unresolved_total", "ms_total", "ms_hist", "ms_sort", "ms_doubling", "period", "chain_items")
+keys = ("path", "radix_passes", "text_rounds", "doubling_rounds", "unresolved_initial", "unresolved_total", "seg_big_items", "ms_total", "ms_hist", "ms_sort", "ms_doubling", "period", "chain_items")
 print(json.dumps({"n": int(x.size), **{k: st[k] for k in keys}, "sa_lf_consistent": bool(ok), "round_trip": bool((back == x).all()),
                   "inverse_ms": round(si["ms_total"], 3), "forward_MBps": round(x.size / 1e6 / (st["ms_total"] * 1e-3), 1)}))
