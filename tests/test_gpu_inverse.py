@@ -24,16 +24,14 @@ def test_round_trip_gpu_only(archon):
         assert (archon.inverse(bwt, base) == x).all(), shape
 
 
-def test_inverse_rejects_non_bwt(archon):
-    """a byte string that is not a BWT: the LF walk does not close over all rows"""
+def test_inverse_rejects_non_bwt(archon, oracle):
+    """a byte string that is not a BWT: the LF walk does not close over all rows (the oracle's walk says so too)"""
     bad = np.frombuffer(b"abab", np.uint8)   # LF permutation of "abab" with base 0 has two cycles
     import ctypes
+    assert oracle.inverse(bad, 0)[0] != 0
     out = np.empty(4, np.uint8)
     rc = archon.lib().archon_hip_inverse(ctypes.c_void_p(bad.ctypes.data), 4, 0, ctypes.c_void_p(out.ctypes.data), 0)
-    assert rc in (archon.E_CORRUPT, archon.OK)
-    if rc == archon.OK:   # if it happens to close, it must round-trip
-        _, b2, base2 = archon.forward(out, want_sa=False)
-        assert base2 == 0 and (b2 == bad).all()
+    assert rc == archon.E_CORRUPT
     rc = archon.lib().archon_hip_inverse(ctypes.c_void_p(bad.ctypes.data), 4, 7, ctypes.c_void_p(out.ctypes.data), 0)
     assert rc == archon.E_ARG
 
