@@ -727,9 +727,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         uint64_t *kS = in_b ? B.keyB : B.keyA;
         uint32_t *vS = in_b ? B.valB : B.valA;
         e2 = tm.mark();
-        hipLaunchKernelGGL(fwd::k_flag_boundaries, dim3(g256), dim3(256), 0, s, kS, n, B.v, 8u * (8u - key_bytes));
-        hipLaunchKernelGGL(fwd::k_bwt_from_keys, dim3(g256), dim3(256), 0, s, kS, vS, n, sa, d_bwt, d_base);
-        c->launches += 2;
+        hipLaunchKernelGGL(fwd::k_bwt_from_keys, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, kS, vS, n, sa, d_bwt, d_base, B.v, 8u * (8u - key_bytes));
+        c->launches += 1;
         e3 = e2;
     }
 
