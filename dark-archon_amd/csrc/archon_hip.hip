@@ -513,7 +513,9 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     const uint32_t *d_skip = &B.prep->skip;
     // The byte histogram of the block comes with the two-byte count: its second-byte column sums are the bytes
     // x[0..n-2] plus the 0xFF in front of x[0]; the host adds x[n-1] and removes the pad (alphabet detection below).
+    bool have_byte_counts = false;               // h_mail[128..383] + h_mail[512] hold the count's byte histogram of THIS block
     auto fetch_byte_counts = [&]() -> int {
+        have_byte_counts = true;
         c->h_mail[512] = 0;
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 128, B.prep->cntA, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 512, d_x + (n - 1), 1, hipMemcpyDeviceToHost, s));
@@ -709,6 +711,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         // ---- first stage for heavily skewed blocks: LSB passes on packed 7-byte keys ----
         // alphabet compaction: with <= 16 distinct bytes the key holds 56/bits symbols
         const bool packed = sigma <= 16 && !getenv("ARCHON_NO_PACK");
+        static thread_local uint32_t hist_given[8 * 256];
+        bool use_given = false;
         if (packed) {
             h0 = 56 / bits;
             hipLaunchKernelGGL(fwd::k_init_keys_packed, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, d_lut, bits, h0,
@@ -716,14 +720,38 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             st.alphabet_bits = bits;
             h0 = (8 * key_bytes) / bits;            // symbols the sorted key bytes hold
         } else {
-            hipLaunchKernelGGL(fwd::k_init_keys, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, B.keyA, B.valA);
             h0 = key_bytes;
+            // Digit histograms without a sweep over the keys: key byte q (q = 1 is the top byte) of item s is x[s-q], or
+            // 0xFF where s < q; over s = 1..n that is the byte histogram of x[0 .. n-q] plus q-1 pads.  The byte histogram
+            // of x came with the two-byte count (fetch_byte_counts); the last bytes of x are fetched here.
+            if (have_byte_counts && n >= 8) {
+                uint32_t H[256];
+                const uint32_t last_byte = c->h_mail[512] & 0xFFu;
+                for (uint32_t v = 0; v < 256; ++v) H[v] = c->h_mail[128 + v] - (v == 0xFFu ? 1u : 0u) + (v == last_byte ? 1u : 0u);
+                ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 520, d_x + (n - 8), 8, hipMemcpyDeviceToHost, s));
+                ARCHON_HIP_TRY(hipStreamSynchronize(s));
+                const uint8_t *tail = reinterpret_cast<const uint8_t *>(c->h_mail + 520);      // x[n-8 .. n-1]
+                for (uint32_t q = 1; q <= 7; ++q) {
+                    uint32_t *hq = hist_given + (8 - q) * 256;                               // pass p = 8 - q sorts on key byte q
+                    memcpy(hq, H, sizeof H);
+                    for (uint32_t j = n - q + 1; j < n; ++j) --hq[tail[j - (n - 8)]];        // bytes past x[n-q] are no digit of depth q
+                    hq[0xFF] += q - 1;
+                }
+                use_given = true;
+            }
         }
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 2;
         bool in_b = false;
         const uint32_t pass_mask = (0xFFu << (8 - key_bytes)) & 0xFEu;          // the top key_bytes bytes; byte 0 is payload
-        ARCHON_TRY(rs::sort_pairs(s, B.sc, B.keyA, B.valA, B.keyB, B.valB, n, pass_mask, &in_b, &st.radix_passes, &c->launches, &pt));
+        // (plain bytes with the histograms in hand: the first pass that runs makes the pairs from the text itself)
+        const bool from_text = !packed && use_given;
+        if (!packed && !from_text)
+            hipLaunchKernelGGL(fwd::k_init_keys, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, B.keyA, B.valA);
+        ARCHON_TRY(rs::sort_pairs(s, B.sc, B.keyA, B.valA, B.keyB, B.valB, n, pass_mask, &in_b, &st.radix_passes, &c->launches, &pt,
+                                  use_given ? hist_given : nullptr, from_text ? d_x : nullptr));
+        if (from_text && st.radix_passes == 0)          // every digit constant: no pass ran, the pairs still have to exist
+            hipLaunchKernelGGL(fwd::k_init_keys, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, B.keyA, B.valA);
         uint64_t *kS = in_b ? B.keyB : B.keyA;
         uint32_t *vS = in_b ? B.valB : B.valA;
         e2 = tm.mark();
