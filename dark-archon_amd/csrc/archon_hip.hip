@@ -153,7 +153,7 @@ struct FwdBuf {
 // first-stage order, v[i] = i at the first row of every group of equal h-byte keys and 0
 // elsewhere.  Runs scan -> scatter_rank -> doubling rounds -> sa_to_bwt.
 static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, uint32_t n, uint32_t *sa, uint32_t h0,
-                         uint8_t *d_bwt, uint32_t *d_base, archon_hip_stats &st, uint32_t p_hint = 0)
+                         uint8_t *d_bwt, uint32_t *d_base, archon_hip_stats &st, uint32_t p_hint = 0, bool ws_ready = true)
 {
     const uint32_t g256 = div_up(n, 256);
 #ifdef ARCHON_EXPERIMENTS
@@ -170,15 +170,13 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     auto trace = [](const char *) {};
 #endif
     trace("enter");
-    ARCHON_TRY(launch_scan<1>(s, B.v, B.v, n, B.scan_tmp, nullptr));
-    hipLaunchKernelGGL(fwd::k_keep_flags, dim3(g256), dim3(256), 0, s, B.v, n, B.keep);
     uint32_t *d_total = B.small + 600;
-    ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, n, B.scan_tmp, d_total));
     ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     ARCHON_HIP_TRY(hipStreamSynchronize(s));
-    c->launches += 7;
     uint32_t m = c->h_mail[0];
     st.unresolved_initial = m;
+    bool compacted = ws_ready;                   // k_first_groups left the working set in upos/ug/uitem[0] (or only counted it)
+    bool keep_ready = false;                     // B.keep / B.dst describe the current tied set
     trace("scan + keep + scan");
     // long-repeat defence: when much of the block is tied and one neighbour gap dominates the tied groups,
     // settle the periodic runs directly (forward.hiph, k_chain_*) before any doubling round
@@ -186,7 +184,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         uint32_t p = p_hint;
         bool dominant = p_hint != 0;        // the driver's period probe already named the period (and the groups may be unordered)
         if (!dominant) {
-            uint32_t *tab = B.upos[0];                      // 2 * kGapSlots words; upos is idle until the compaction
+            uint32_t *tab = B.upos[1];                      // 2 * kGapSlots words; the second working-set buffers are idle
             ARCHON_HIP_TRY(hipMemsetAsync(tab, 0, 2 * fwd::kGapSlots * sizeof(uint32_t), s));
             hipLaunchKernelGGL(fwd::k_gap_sample, dim3(div_up(div_up(n, fwd::kGapStride), 256)), dim3(256), 0, s, sa, B.v, n, tab);
             ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, tab, 2 * fwd::kGapSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -203,7 +201,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         }
         if (p >= 1 && p < n && dominant) {
             uint32_t *brk = B.rank, *ginfo = B.dst, *gend = B.keep, *settled = B.small + 601;
-            uint32_t *gmin = B.ug[0], *gmax = B.ug[1];          // idle until the compaction
+            uint32_t *gmin = B.ug[1], *gmax = B.uitem[1];       // the second working-set buffers are idle
             hipLaunchKernelGGL(fwd::k_period_breaks, dim3(g256), dim3(256), 0, s, d_x, n, p, brk);
             ARCHON_TRY(launch_scan<1>(s, brk, brk, n, B.scan_tmp, nullptr));
             hipLaunchKernelGGL(fwd::k_chain_init, dim3(g256), dim3(256), 0, s, B.v, n, gmin, gmax, ginfo);
@@ -220,7 +218,9 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             c->launches += 8;
             if (c->h_mail[1] >= m) {
                 m = 0;                          // every tied row was settled: nothing to count or compact
-            } else {
+            } else if (c->h_mail[1] != 0 || !compacted) {
+                compacted = false;
+                keep_ready = true;
                 // the tied set again, without the settled groups
                 hipLaunchKernelGGL(fwd::k_keep_flags, dim3(g256), dim3(256), 0, s, B.v, n, B.keep);
                 ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, n, B.scan_tmp, d_total));
@@ -240,10 +240,17 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     uint32_t *vT = B.valA, *vS = B.valB;
     uint32_t h = h0;
     if (m) {
-        hipLaunchKernelGGL(fwd::k_compact_first, dim3(g256), dim3(256), 0, s, B.keep, B.dst, B.v, sa, n, B.upos[0], B.ug[0],
-                           B.uitem[0]);
+        if (!compacted) {
+            if (!keep_ready) {                   // the working set was only counted and the run shortcut did not run after all
+                hipLaunchKernelGGL(fwd::k_keep_flags, dim3(g256), dim3(256), 0, s, B.v, n, B.keep);
+                ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, n, B.scan_tmp, d_total));
+                c->launches += 3;
+            }
+            hipLaunchKernelGGL(fwd::k_compact_first, dim3(g256), dim3(256), 0, s, B.keep, B.dst, B.v, sa, n, B.upos[0], B.ug[0],
+                               B.uitem[0]);
+            ++c->launches;
+        }
         ARCHON_HIP_TRY(hipMemcpyAsync(B.uinit, B.upos[0], (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-        ++c->launches;
     }
     // Text rounds: while few items are tied, key them on the next four bytes of the text instead of on ranks -- no
     // inverse suffix array yet (its 4N-byte scatter costs more than a whole round on a small working set).  They stop
@@ -444,7 +451,6 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         d_x = B.xa;
     }
     uint32_t *sa = d_sa_user ? d_sa_user : B.sa_own;
-    const uint32_t g256 = div_up(n, 256);
 
     StageTimer tm(c, 0, s);
     StageTimer pt(c, 24, s);
@@ -578,6 +584,22 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         big_items = c->h_mail[64];
         return ARCHON_OK;
     };
+    // entry of the general stage (k_first_groups): clean SA, group starts and the compacted working set in one sweep
+    auto first_groups = [&](int mode, const uint64_t *keys, const uint32_t *items, uint32_t shift, bool write_ws) -> int {
+        unsigned long long *fg_status = reinterpret_cast<unsigned long long *>(B.sc.d_status);
+        const uint32_t tiles = div_up(n, fwd::kFgTile);
+        ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
+        ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
+        if (mode == 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_first_groups<0>), dim3(tiles), dim3(256), 0, s, keys, items, shift, n, sa, d_bwt, d_base, B.v,
+                               B.upos[0], B.ug[0], B.uitem[0], small + 600, fg_status, B.sc.d_ticket, B.sc.d_err, write_ws ? 1u : 0u);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_first_groups<1>), dim3(tiles), dim3(256), 0, s, keys, items, shift, n, sa, d_bwt, d_base, B.v,
+                               B.upos[0], B.ug[0], B.uitem[0], small + 600, fg_status, B.sc.d_ticket, B.sc.d_err, write_ws ? 1u : 0u);
+        ARCHON_HIP_TRY(hipGetLastError());
+        ++c->launches;
+        return ARCHON_OK;
+    };
     int forced = -1;                             // ARCHON_FORCE_PATH (tests): 0 = 7-pass route, 1 = streaming stage
     if (const char *f = getenv("ARCHON_FORCE_PATH")) forced = atoi(f) ? 1 : 0;
     int path;
@@ -688,7 +710,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     if (e2 < 0) e2 = e1;
     if (e3 < 0) e3 = e1;
     e4 = e1;
-    bool need_general = true;
+    bool need_general = true, ws_ready = true;
     uint32_t h0 = fwd::kKeyBytes;
     if (path == 1) {
         st.radix_passes = 2;
@@ -702,9 +724,9 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, &d_ctl->base_id, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         } else {
             h0 = (h_ctl.min_depth < 5 ? h_ctl.min_depth : 5) * (uint32_t)Q;     // key bytes -> symbols
-            hipLaunchKernelGGL(bs::k_flags_from_sa, dim3(g256), dim3(256), 0, s, sa, n, B.v);
+            ws_ready = period_hint == 0;
+            ARCHON_TRY(first_groups(1, nullptr, nullptr, 0, ws_ready));
             ARCHON_HIP_TRY(hipMemcpyAsync(d_base, &d_ctl->base_id, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-            ++c->launches;
         }
         e4 = e3;
     } else {
@@ -755,13 +777,13 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         uint64_t *kS = in_b ? B.keyB : B.keyA;
         uint32_t *vS = in_b ? B.valB : B.valA;
         e2 = tm.mark();
-        hipLaunchKernelGGL(fwd::k_bwt_from_keys, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, kS, vS, n, sa, d_bwt, d_base, B.v, 8u * (8u - key_bytes));
-        c->launches += 1;
+        ws_ready = key_bytes == fwd::kKeyBytes;          // a periodic block: the run shortcut will empty the working set
+        ARCHON_TRY(first_groups(0, kS, vS, 8u * (8u - key_bytes), ws_ready));
         e3 = e2;
     }
 
     if (need_general) {
-        ARCHON_TRY(general_stage(c, s, B, d_x, n, sa, h0, d_bwt, d_base, st, period_hint));
+        ARCHON_TRY(general_stage(c, s, B, d_x, n, sa, h0, d_bwt, d_base, st, period_hint, ws_ready));
         e4 = tm.mark();
         ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, d_base, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
