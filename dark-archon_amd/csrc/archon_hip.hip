@@ -310,22 +310,21 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     };
     // the rest of a round: items and group starts back into the tables, survivors compacted into the next working set
     auto round_finish = [&](bool text, uint32_t mm, int cu, uint32_t *vR, uint32_t *m2_out) -> int {
-        const uint32_t gm = div_up(mm, 256);
+        unsigned long long *fg_status = reinterpret_cast<unsigned long long *>(B.sc.d_status);
+        const uint32_t tiles = div_up(mm, fwd::kFgTile);
+        ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
+        ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
         if (text)
-            hipLaunchKernelGGL(fwd::k_round_update_text, dim3(gm), dim3(256), 0, s, vR, B.upos[cu], B.vw, mm, sa, B.v, B.keep);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_finish<true>), dim3(tiles), dim3(256), 0, s, vR, B.upos[cu], B.vw, mm, sa, B.v,
+                               B.upos[cu ^ 1], B.ug[cu ^ 1], B.uitem[cu ^ 1], d_total, fg_status, B.sc.d_ticket, B.sc.d_err);
         else
-            hipLaunchKernelGGL(fwd::k_round_update, dim3(gm), dim3(256), 0, s, vR, B.upos[cu], B.vw, mm, sa, B.rank, B.keep);
-        ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, mm, B.scan_tmp, d_total));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_finish<false>), dim3(tiles), dim3(256), 0, s, vR, B.upos[cu], B.vw, mm, sa, B.rank,
+                               B.upos[cu ^ 1], B.ug[cu ^ 1], B.uitem[cu ^ 1], d_total, fg_status, B.sc.d_ticket, B.sc.d_err);
+        ARCHON_HIP_TRY(hipGetLastError());
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
-        c->launches += 4;
+        ++c->launches;
         *m2_out = c->h_mail[0];
-        if (*m2_out) {
-            hipLaunchKernelGGL(fwd::k_compact_round, dim3(gm), dim3(256), 0, s, B.keep, B.dst, B.upos[cu], B.vw, vR, mm,
-                               B.upos[cu ^ 1], B.ug[cu ^ 1], B.uitem[cu ^ 1]);
-            ARCHON_HIP_TRY(hipGetLastError());
-            ++c->launches;
-        }
         return ARCHON_OK;
     };
     const bool text_ok = !getenv("ARCHON_NO_TEXT_ROUNDS");
