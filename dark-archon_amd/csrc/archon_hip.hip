@@ -315,10 +315,10 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
         ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
         if (text)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_finish<true>), dim3(tiles), dim3(256), 0, s, vR, B.upos[cu], B.vw, mm, sa, B.v,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_finish<true>), dim3(tiles), dim3(256), 0, s, vR, B.upos[cu], B.vw, B.ug[cu], mm, sa, B.v,
                                B.upos[cu ^ 1], B.ug[cu ^ 1], B.uitem[cu ^ 1], d_total, fg_status, B.sc.d_ticket, B.sc.d_err);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_finish<false>), dim3(tiles), dim3(256), 0, s, vR, B.upos[cu], B.vw, mm, sa, B.rank,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_finish<false>), dim3(tiles), dim3(256), 0, s, vR, B.upos[cu], B.vw, B.ug[cu], mm, sa, B.rank,
                                B.upos[cu ^ 1], B.ug[cu ^ 1], B.uitem[cu ^ 1], d_total, fg_status, B.sc.d_ticket, B.sc.d_err);
         ARCHON_HIP_TRY(hipGetLastError());
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
