@@ -346,7 +346,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     if (m) {
         // ranks are needed only now (4N random stores): every item, not just the tied ones
         trace("before scatter_rank");
-        hipLaunchKernelGGL(fwd::k_scatter_rank, dim3(g256), dim3(256), 0, s, sa, B.v, n, sa, B.rank, B.keep);
+        hipLaunchKernelGGL(fwd::k_scatter_rank, dim3(g256), dim3(256), 0, s, sa, B.v, n, B.rank);
         ++c->launches;
         trace("scatter_rank");
     }
