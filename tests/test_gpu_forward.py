@@ -457,3 +457,23 @@ def test_two_byte_count_hot_bins(archon, oracle):
     sa, bwt, base = archon.forward(y)
     P, B, b0 = oracle.forward(y)
     assert (sa == P).all() and (bwt == B).all() and base == b0
+
+
+@pytest.mark.parametrize("shape,n", [("text", 300001), ("random", 1 << 20), ("dna", 250000), ("a", 90001), ("motif", 200003)])
+def test_misaligned_device_buffers(archon, oracle, shape, n):
+    """caller buffers at odd addresses (text + 3 bytes, SA + 1 word, BWT + 1 byte): every route has to fall back from its
+    16-byte loads and stores (the library copies a misaligned text; SA and BWT are written where they are)"""
+    import torch
+    x = S.gen_shape(shape, n)
+    if shape == "dna":
+        x = np.concatenate([x[:100000], x[:100000], x[:50000]])      # repeats: the streaming stage leaves ties for the rounds
+    xb = torch.zeros(n + 16, dtype=torch.uint8, device="cuda")
+    xb[3:3 + n] = torch.from_numpy(x).cuda()
+    sab = torch.zeros(n + 8, dtype=torch.int32, device="cuda")
+    bwb = torch.zeros(n + 8, dtype=torch.uint8, device="cuda")
+    base_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+    archon.forward_dev(xb[3:3 + n], sab[1:1 + n], bwb[1:1 + n], base_t)
+    P, B, b0 = oracle.forward(x)
+    assert (sab[1:1 + n].cpu().numpy().view(np.uint32) == P).all()
+    assert (bwb[1:1 + n].cpu().numpy() == B).all() and int(base_t.item()) == b0
+    assert int(sab[0].item()) == 0 and int(sab[1 + n].item()) == 0 and int(bwb[0].item()) == 0 and int(bwb[1 + n].item()) == 0
