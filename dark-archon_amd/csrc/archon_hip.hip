@@ -202,7 +202,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         if (p >= 1 && p < n && dominant) {
             uint32_t *brk = B.rank, *ginfo = B.dst, *gend = B.keep, *settled = B.small + 601;
             uint32_t *gmin = B.ug[1], *gmax = B.uitem[1];       // the second working-set buffers are idle
-            hipLaunchKernelGGL(fwd::k_period_breaks, dim3(g256), dim3(256), 0, s, d_x, n, p, brk);
+            hipLaunchKernelGGL(fwd::k_period_breaks, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, p, brk);
             ARCHON_TRY(launch_scan<1>(s, brk, brk, n, B.scan_tmp, nullptr));
             hipLaunchKernelGGL(fwd::k_chain_init, dim3(g256), dim3(256), 0, s, B.v, n, gmin, gmax, ginfo);
             ARCHON_HIP_TRY(hipMemsetAsync(settled, 0, sizeof(uint32_t), s));
@@ -489,7 +489,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // bucket-per-workgroup pass B (Prep::aligned) needs 256 workgroups and enough tiles per bucket to matter
     const uint32_t allow_aligned = (n >= (1u << 24) && !getenv("ARCHON_NO_ALIGNED")) ? 1u : 0u;
     int e1 = -1;
-    auto count16 = [&](int Q, const uint8_t *src, bool force_stream, bool probe = false) -> int {
+    auto count16 = [&](int Q, const uint8_t *src, bool force_stream, bool probe = false, bool hot = false) -> int {
         uint32_t *d_suspect = probe ? &B.prep->suspect : nullptr;
         ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, (size_t)(reinterpret_cast<char *>(&B.prep->rowtot[0]) - reinterpret_cast<char *>(B.hist16)), s));
         // the count runs with at most 256 workgroups per half: with more pass ranges each workgroup covers several of
@@ -498,7 +498,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         const uint32_t nparts = div_up(R, sub);
         const dim3 grid(nparts), block(bs::kH16Block);
         // B.hist16 (zeroed above) first serves as the spill table of the count, then receives the totals (k_rows_total)
-        if (Q == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<1>), grid, block, 0, s, src, n, B.h16part, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
+        if (Q == 1 && hot) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<1, true>), grid, block, 0, s, src, n, B.h16part, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
+        else if (Q == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<1>), grid, block, 0, s, src, n, B.h16part, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
         else if (Q == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<2>), grid, block, 0, s, src, n, B.h16part, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
         else if (Q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<4>), grid, block, 0, s, src, n, B.h16part, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.h16part, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
@@ -661,7 +662,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             const bool single_runs = pp <= 2 || (count_ok && (uint64_t)h_ctl.max_bucket * 2 * pp <= (uint64_t)n * 3);
             if (forced < 0 && single_runs && !getenv("ARCHON_NO_PERIOD_STREAM")) {
                 period_hint = pp;               // the streaming passes keep no order inside a bucket: no gap sampling there
-                ARCHON_TRY(count16(1, d_x, true));
+                ARCHON_TRY(count16(1, d_x, true, false, true));
                 ARCHON_TRY(streaming(1, d_x, true));
                 path = 1;
                 Q = 1;
