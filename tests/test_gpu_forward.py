@@ -477,3 +477,19 @@ def test_misaligned_device_buffers(archon, oracle, shape, n):
     assert (sab[1:1 + n].cpu().numpy().view(np.uint32) == P).all()
     assert (bwb[1:1 + n].cpu().numpy() == B).all() and int(base_t.item()) == b0
     assert int(sab[0].item()) == 0 and int(sab[1 + n].item()) == 0 and int(bwb[0].item()) == 0 and int(bwb[1 + n].item()) == 0
+
+
+@pytest.mark.parametrize("ranges", ["300", "1024"])
+def test_periodic_blocks_with_many_pass_ranges(archon, oracle, monkeypatch, ranges):
+    """the N > 1 configuration of bench.py (many pass ranges, no bucket mode) on the periodic route: hot-digit ranking,
+    deferred buckets and the run shortcut with the passes cut into odd ranges"""
+    monkeypatch.setenv("ARCHON_PASS_RANGES", ranges)
+    monkeypatch.setenv("ARCHON_NO_ALIGNED", "1")
+    rng = np.random.default_rng(5)
+    for x in (np.tile(np.frombuffer(b"ab", np.uint8), 1 << 20), np.full(3000001, 97, np.uint8),
+              np.tile(rng.integers(0, 256, size=37, dtype=np.uint8), 60000)):
+        sa, bwt, base = archon.forward(x)
+        st = archon.stats()
+        P, B, b0 = oracle.forward(x)
+        assert (sa == P).all() and (bwt == B).all() and base == b0
+        assert st["period"] in (1, 2, 37) and st["doubling_rounds"] == 0
