@@ -355,6 +355,17 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         ++st.doubling_rounds;
         uint32_t *vR = nullptr, m2 = 0;
 #ifdef ARCHON_EXPERIMENTS
+        if (getenv("ARCHON_TRACE_GROUPS")) {
+            unsigned long long *gh = reinterpret_cast<unsigned long long *>(B.scan_tmp);
+            ARCHON_HIP_TRY(hipMemsetAsync(gh, 0, 32 * sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(fwd::k_group_hist, dim3(div_up(m, 256)), dim3(256), 0, s, B.ug[cur], m, gh);
+            unsigned long long hh[32];
+            ARCHON_HIP_TRY(hipMemcpyAsync(hh, gh, sizeof hh, hipMemcpyDeviceToHost, s));
+            ARCHON_HIP_TRY(hipStreamSynchronize(s));
+            fprintf(stderr, "groups h=%u:", h);
+            for (int b = 1; b < 32; ++b) if (hh[b]) fprintf(stderr, " 2^%d:%.1fM", b, hh[b] / 1e6);
+            fprintf(stderr, "\n");
+        }
         const uint64_t big0 = st.seg_big_items;
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         const auto t0 = std::chrono::steady_clock::now();
