@@ -669,10 +669,11 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             // two bytes at two places of the motif) is no run, and sorting it out at depth 2 costs more than a third key
             // byte.  The two-byte count tells: a single run holds n / p items.  (Periods 1 and 2 cannot collide.)
             const uint32_t pp = c->h_mail[0];
+            if (!getenv("ARCHON_NO_PERIOD_HINT")) period_hint = pp;     // the run shortcut need not sample neighbour gaps for it
             const bool count_ok = forced < 0 && !h_ctl.suspect;
             const bool single_runs = pp <= 2 || (count_ok && (uint64_t)h_ctl.max_bucket * 2 * pp <= (uint64_t)n * 3);
             if (forced < 0 && single_runs && !getenv("ARCHON_NO_PERIOD_STREAM")) {
-                period_hint = pp;               // the streaming passes keep no order inside a bucket: no gap sampling there
+                period_hint = pp;               // (the streaming passes keep no order inside a bucket: gap sampling would not work)
                 ARCHON_TRY(count16(1, d_x, true, false, true));
                 ARCHON_TRY(streaming(1, d_x, true));
                 path = 1;

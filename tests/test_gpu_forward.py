@@ -244,10 +244,14 @@ def test_long_repeats_use_the_shortcut(archon, monkeypatch, route):
     assert st["path"] == (1 if route == "streaming" else 0)
 
 
+@pytest.mark.parametrize("hint", ["probe", "gaps"])
 @pytest.mark.parametrize("name", ["a", "ab", "motif1000", "motif_with_glitches", "three_runs", "nested"])
-def test_long_repeats_lsb_route(archon, oracle, name, monkeypatch):
-    """the same gauntlet with the periodic blocks kept on the 7-pass route (ordered groups, gap sampling)"""
+def test_long_repeats_lsb_route(archon, oracle, name, hint, monkeypatch):
+    """the same gauntlet with the periodic blocks kept on the 7-pass route (ordered groups): the period from the driver's
+    probe, or -- probe's answer withheld -- from a sample of the neighbour gaps inside the tied groups"""
     monkeypatch.setenv("ARCHON_NO_PERIOD_STREAM", "1")
+    if hint == "gaps":
+        monkeypatch.setenv("ARCHON_NO_PERIOD_HINT", "1")
     x = _repeat_cases()[name]
     sa, bwt, base = archon.forward(x)
     P, B, b0 = oracle.forward(x)
