@@ -202,16 +202,18 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         if (p >= 1 && p < n && dominant) {
             uint32_t *brk = B.rank, *ginfo = B.dst, *gend = B.keep, *settled = B.small + 601;
             uint32_t *gmin = B.ug[1], *gmax = B.uitem[1];       // the second working-set buffers are idle
-            hipLaunchKernelGGL(fwd::k_period_breaks, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, p, brk);
+            uint32_t *d_lastbrk = B.small + 606;
+            ARCHON_HIP_TRY(hipMemsetAsync(d_lastbrk, 0, sizeof(uint32_t), s));
+            hipLaunchKernelGGL(fwd::k_period_breaks, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, p, brk, d_lastbrk);
             ARCHON_TRY(launch_scan<1>(s, brk, brk, n, B.scan_tmp, nullptr));
             hipLaunchKernelGGL(fwd::k_chain_init, dim3(g256), dim3(256), 0, s, B.v, n, gmin, gmax, ginfo);
             ARCHON_HIP_TRY(hipMemsetAsync(settled, 0, sizeof(uint32_t), s));
             trace("breaks + scan + memsets");
             hipLaunchKernelGGL(fwd::k_chain_minmax, dim3(div_up(n, fwd::kChainRows)), dim3(256), 0, s, sa, B.v, n, gmin, gmax);
             trace("chain_minmax");
-            hipLaunchKernelGGL(fwd::k_chain_probe, dim3(g256), dim3(256), 0, s, d_x, sa, B.v, brk, n, p, gmin, gmax, ginfo, gend);
+            hipLaunchKernelGGL(fwd::k_chain_probe, dim3(g256), dim3(256), 0, s, d_x, sa, B.v, brk, n, p, gmin, gmax, d_lastbrk, ginfo, gend);
             trace("chain_probe");
-            hipLaunchKernelGGL(fwd::k_chain_apply, dim3(g256), dim3(256), 0, s, sa, B.v, ginfo, gend, gmin, gmax, brk, d_x, n, p, d_bwt, d_base, settled);
+            hipLaunchKernelGGL(fwd::k_chain_apply, dim3(g256), dim3(256), 0, s, sa, B.v, ginfo, gend, gmin, gmax, brk, d_lastbrk, d_x, n, p, d_bwt, d_base, settled);
             trace("chain_apply");
             ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 1, settled, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             ARCHON_HIP_TRY(hipStreamSynchronize(s));
