@@ -497,3 +497,26 @@ def test_periodic_blocks_with_many_pass_ranges(archon, oracle, monkeypatch, rang
         P, B, b0 = oracle.forward(x)
         assert (sa == P).all() and (bwt == B).all() and base == b0
         assert st["period"] in (1, 2, 37) and st["doubling_rounds"] == 0
+
+
+def test_tie_heavy_block_full_size(archon):
+    """two copies of a 128 MiB random block: every row is tied with its twin beyond the streaming stage's five key bytes, so
+    every 16-bit bucket lists ~2048 tie groups -- nearly as many as its LDS list can hold: the per-bucket booking, the
+    tie-list cap, the run shortcut at distance N/2 and the rounds behind it.  Size-independent checks."""
+    import torch
+    half = S.gen_random(128 << 20)
+    x = np.concatenate([half, half])
+    n = x.size
+    x_t = torch.from_numpy(x).cuda()
+    del x, half
+    sa_t = torch.empty(n, dtype=torch.int32, device="cuda")
+    bwt_t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    base_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+    archon.forward_dev(x_t, sa_t, bwt_t, base_t)
+    st = archon.stats()
+    assert st["path"] == 1 and st["tie_items"] >= n // 2 - 16
+    assert st["ms_local_sort"] < 10.0          # one global atomic per tie GROUP made this 70+ ms
+    assert archon.validate_dev(x_t, sa_t)
+    out_t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    archon.inverse_dev(bwt_t, int(base_t.item()), out_t)
+    assert torch.equal(out_t, x_t)
