@@ -213,7 +213,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             trace("chain_minmax");
             hipLaunchKernelGGL(fwd::k_chain_probe, dim3(div_up(n, fwd::kChainRows)), dim3(256), 0, s, d_x, sa, B.v, brk, n, p, gmin, gmax, d_lastbrk, ginfo, gend);
             trace("chain_probe");
-            hipLaunchKernelGGL(fwd::k_chain_apply, dim3(g256), dim3(256), 0, s, sa, B.v, ginfo, gend, gmin, gmax, brk, d_lastbrk, d_x, n, p, d_bwt, d_base, settled);
+            hipLaunchKernelGGL(fwd::k_chain_apply, dim3(div_up(n, fwd::kChainRows)), dim3(256), 0, s, sa, B.v, ginfo, gend, gmin, gmax, brk, d_lastbrk, d_x, n, p, d_bwt, d_base, settled);
             trace("chain_apply");
             ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 1, settled, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             ARCHON_HIP_TRY(hipStreamSynchronize(s));
