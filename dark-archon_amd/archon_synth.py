@@ -89,7 +89,99 @@ def gen_motif(n, motif_len=1000, seed=SEED_BASE + 3):
     return gen_repeat(n, gen_random(motif_len, seed).tobytes())
 
 
-SHAPES = ("text", "random", "dna", "a", "ab", "motif")
+# ---- "prose": natural-text-like block in the deep-LCP regime ----------------------------
+# Sentences drawn from a Zipf-ranked set of templates over a Zipf-ranked vocabulary (most slots keep the
+# template's word, some take one of four alternatives); one paragraph in eight is one of 256 fixed boilerplate
+# paragraphs (licence headers); then a number of long passages are copied to other places (vendored copies).  Measured on 64 MiB (tools/lcp_stats.c): see DESIGN.md 3.2.  Pure integer
+# arithmetic on splitmix64 words, vectorised per chunk of sentences.
+_PROSE_V = 4096          # vocabulary
+_PROSE_T = 2048          # sentence templates
+_PROSE_SLOTS = 16
+_LETTERS = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxq", dtype=np.uint8)      # 25 letters, index (p*q)//39 with p,q < 32
+_prose_tables = {}
+
+
+def _prose_build(seed):
+    if seed in _prose_tables:
+        return _prose_tables[seed]
+    u = np.uint64
+    # vocabulary: word w = 2..9 letters + ' '; row _PROSE_V is the sentence end ".\n"
+    r = splitmix64_words(seed ^ 0x5EED0001, 0, 2 * _PROSE_V).reshape(_PROSE_V, 2)
+    wl = (2 + (r[:, 0] & u(7))).astype(np.int64)
+    words = np.full((_PROSE_V + 1, 10), ord(" "), dtype=np.uint8)
+    for k in range(9):
+        p = (r[:, 1] >> u(10 * (k % 6))) & u(31)
+        q = ((r[:, 1] >> u(10 * (k % 6) + 5)) ^ (r[:, 0] >> u(8 + 3 * k))) & u(31)
+        words[:_PROSE_V, k] = _LETTERS[((p * q) // u(39)).astype(np.intp)]
+    cols = np.arange(10)[None, :]
+    words[:_PROSE_V][cols >= wl[:, None]] = ord(" ")
+    wl = np.concatenate([wl + 1, [2]])                      # + the trailing space; ".\n"
+    words[_PROSE_V, 0] = ord(".")
+    words[_PROSE_V, 1] = ord("\n")
+    # templates: slot count 6..16, per slot a base word and four alternatives, ids skewed to the small (common) ones
+    r = splitmix64_words(seed ^ 0x5EED0002, 0, _PROSE_T * _PROSE_SLOTS * 3).reshape(_PROSE_T, _PROSE_SLOTS, 3)
+
+    def wid(a, sh):
+        return ((((a >> u(sh)) & u(4095)) * ((a >> u(sh + 12)) & u(4095))) >> u(12)).astype(np.int64)
+
+    base = wid(r[:, :, 0], 0)
+    alt = np.stack([wid(r[:, :, 1], 0), wid(r[:, :, 1], 24), wid(r[:, :, 2], 0), wid(r[:, :, 2], 24)], axis=2)
+    nslots = (6 + (r[:, 0, 0] >> u(48)) % u(11)).astype(np.int64)
+    _prose_tables[seed] = (words, wl, base, alt, nslots)
+    return _prose_tables[seed]
+
+
+def gen_prose(n, seed=SEED_BASE + 6):
+    """Deep-LCP natural-text-like block: template sentences + copied passages (see the comment above)."""
+    words, wl, base, alt, nslots = _prose_build(seed)
+    u = np.uint64
+    out = np.empty(n + (1 << 21), dtype=np.uint8)
+    fill = 0
+    sent0 = 0
+    per = 1 << 15                                           # sentences per chunk
+    kk = np.arange(_PROSE_SLOTS + 1, dtype=np.int64)[None, :]
+    while fill < n:
+        r = splitmix64_words(seed, 2 * sent0, 2 * per).reshape(per, 2)
+        # boilerplate: one paragraph (8 sentences) in eight repeats one of 256 fixed paragraphs word for word
+        pr = splitmix64_words(seed ^ 0x5EED0004, sent0 // 8, per // 8)
+        bid = ((((pr >> u(8)) & u(0xFFF)) * ((pr >> u(20)) & u(0xFFF))) >> u(16)).astype(np.int64)      # 0..255, skewed
+        fixed = splitmix64_words(seed ^ 0x5EED0005, 0, 256 * 16).reshape(256, 8, 2)[bid].reshape(per, 2)
+        r = np.where(np.repeat((pr & u(7)) == 0, 8)[:, None], fixed, r)
+        sent0 += per
+        t = ((((r[:, 0] & u(0xFFFF)) * ((r[:, 0] >> u(16)) & u(0xFFFF))) >> u(21))).astype(np.int64)
+        ks = np.arange(_PROSE_SLOTS, dtype=np.uint64)[None, :]
+        q = (r[:, 1][:, None] >> (u(2) * ks)) & u(3)
+        a = ((r[:, 0][:, None] >> (u(32) + u(2) * ks)) & u(3)).astype(np.int64)
+        w = np.where(q != 0, base[t], np.take_along_axis(alt[t], a[:, :, None], axis=2)[:, :, 0])
+        ns = nslots[t][:, None]
+        w = np.concatenate([w, np.full((per, 1), _PROSE_V, dtype=np.int64)], axis=1)
+        w = np.where(kk == ns, _PROSE_V, w)                 # the sentence end right after its last slot
+        ids = w[kk <= ns]                                   # row-major: sentence after sentence
+        ln = wl[ids]
+        end = np.cumsum(ln)
+        total = int(end[-1])
+        first = np.repeat(end - ln, ln)
+        col = np.arange(total, dtype=np.int64) - first
+        chunk = words[np.repeat(ids, ln), col]
+        take = min(total, out.size - fill)
+        out[fill:fill + take] = chunk[:take]
+        fill += take
+    x = out[:n].copy()
+    del out
+    # copied passages: lengths log-uniform in [256, 2 Mi), at most n/8; applied in order (later copies may overlap earlier ones)
+    ncopies = max(2, n >> 21) if n >= (1 << 16) else 0
+    r = splitmix64_words(seed ^ 0x5EED0003, 0, 3 * ncopies + 3)
+    for j in range(ncopies):
+        e = 8 + int(r[3 * j] % u(13))
+        ln = (1 << e) + int((r[3 * j] >> u(8)) & u((1 << e) - 1))
+        ln = min(ln, n // 8)
+        src = int(r[3 * j + 1] % u(n - ln))
+        dst = int(r[3 * j + 2] % u(n - ln))
+        x[dst:dst + ln] = x[src:src + ln].copy()
+    return x
+
+
+SHAPES = ("text", "random", "dna", "a", "ab", "motif", "prose")
 
 
 def gen_shape(shape, n, block=0):
@@ -106,4 +198,6 @@ def gen_shape(shape, n, block=0):
         return gen_repeat(n, b"ab")
     if shape == "motif":
         return gen_motif(n, 1000, SEED_BASE + 3 + block)
+    if shape == "prose":
+        return gen_prose(n, SEED_BASE + 6 + block)
     raise ValueError(shape)

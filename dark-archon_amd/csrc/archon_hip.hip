@@ -5,6 +5,7 @@
 #include "radix_sort.hiph"
 #include "bucket_sort.hiph"
 #include "forward.hiph"
+#include "rounds.hiph"
 #include "inverse.hiph"
 
 #include <stdarg.h>
@@ -132,6 +133,7 @@ static size_t forward_arena_bytes(uint32_t n)
     add(sizeof(uint4) * (size_t)bs::kMaxRanges * bs::kTrashWords);
     add(4 * (size_t)bs::kMaxRanges * 32768u);     // partial two-byte counts
     add(4 * 1024);                            // counts, starts, ticket, err, base, totals, TieCtl
+    add(8 * N + 64); add(8 * N + 64); add(8 * N + 64);      // the S lists of the refinement rounds (double-buffered) and the rank log
     return b + 4096;
 }
 
@@ -141,6 +143,7 @@ struct FwdBuf {
     uint32_t *valA, *valB, *rank, *sa_own, *v, *keep, *dst;
     uint32_t *upos[2], *ug[2], *uitem[2], *uinit, *rhist, *vw;
     uint8_t *y;
+    uint2 *slist[2], *rlog;    // rounds.hiph: entries of short groups {row, item | head}, the round's rank updates {item, rank}
     uint32_t *scan_tmp, *hist16, *small;
     bs::Prep *prep;
     uint2 *tie_list;
@@ -329,18 +332,75 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         *m2_out = c->h_mail[0];
         return ARCHON_OK;
     };
+    // ---- the two lists (rounds.hiph): S = entries of groups of at most fwd::kFuMax rows, one fused kernel per round;
+    //      B = the longer groups, on the round_sort / round_finish path above, handed over to S as they split
+    const bool fused_ok = !getenv("ARCHON_NO_FUSED");
+    uint32_t *d_fu = B.small + 700;              // [0] entries appended to the next S list, [1] rank log entries, [2] the next B list
+    uint32_t ms = 0, mb = m;
+    int cs = 0;
+    // triples in buffer `from` (mm of them, in row order) -> short groups appended to S list `cs_out`, the rest to buffer `from ^ 1`
+    auto classify = [&](int from, uint32_t mm, int cs_out) -> int {
+        unsigned long long *fg_status = reinterpret_cast<unsigned long long *>(B.sc.d_status);
+        const uint32_t tiles = div_up(mm, fwd::kClT);
+        ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
+        ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(fwd::k_classify, dim3(tiles), dim3(fwd::kFuLanes), 0, s, B.upos[from], B.ug[from], B.uitem[from], mm, B.slist[cs_out], d_fu,
+                           B.upos[from ^ 1], B.ug[from ^ 1], B.uitem[from ^ 1], d_fu + 2, fg_status, B.sc.d_ticket, B.sc.d_err);
+        ARCHON_HIP_TRY(hipGetLastError());
+        ++c->launches;
+        return ARCHON_OK;
+    };
+    if (m && fused_ok) {
+        ARCHON_HIP_TRY(hipMemsetAsync(d_fu, 0, 3 * sizeof(uint32_t), s));
+        ARCHON_TRY(classify(cur, m, cs));
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_fu, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        ms = c->h_mail[0];
+        mb = c->h_mail[2];
+        cur ^= 1;
+        if (ms + mb != m) { set_error("classification lost entries (%u + %u of %u)", ms, mb, m); return ARCHON_E_INTERNAL; }
+        trace("classify");
+    }
+    // one round over both lists: mode 0 keys on rank[s-h], mode 1 on the next four text bytes
+    auto do_round = [&](int mode, uint32_t hh) -> int {
+        ARCHON_HIP_TRY(hipMemsetAsync(d_fu, 0, 3 * sizeof(uint32_t), s));
+        if (ms) {
+            const dim3 grid(div_up(ms, fwd::kFuT)), block(fwd::kFuLanes);
+            if (mode == 0)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_fused<0>), grid, block, 0, s, B.slist[cs], ms, B.rank, d_x, hh, sa, B.v, B.slist[cs ^ 1], B.rlog, d_fu, B.sc.d_err);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_fused<1>), grid, block, 0, s, B.slist[cs], ms, B.rank, d_x, hh, sa, B.v, B.slist[cs ^ 1], B.rlog, d_fu, B.sc.d_err);
+            ARCHON_HIP_TRY(hipGetLastError());
+            ++c->launches;
+        }
+        uint32_t mb2 = 0;
+        if (mb) {
+            uint32_t *vR = nullptr;
+            ARCHON_TRY(round_sort(mode, mb, hh, cur, &vR));
+            ARCHON_TRY(round_finish(mode == 1, mb, cur, vR, &mb2));
+            if (mb2 && fused_ok) ARCHON_TRY(classify(cur ^ 1, mb2, cs ^ 1));      // what is left of B, back into buffer `cur`
+            else cur ^= 1;
+        }
+        if (mode == 0 && ms) {                  // the S list's rank updates, now that every key of the round has been read
+            hipLaunchKernelGGL(fwd::k_rank_apply, dim3(div_up(ms, 256)), dim3(256), 0, s, B.rlog, d_fu + 1, B.rank);
+            ++c->launches;
+        }
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_fu, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        ms = c->h_mail[0];
+        mb = (mb2 && fused_ok) ? c->h_mail[2] : mb2;
+        cs ^= 1;
+        return ARCHON_OK;
+    };
     const bool text_ok = !getenv("ARCHON_NO_TEXT_ROUNDS");
     while (m && text_ok && (uint64_t)m * 4 <= n && st.text_rounds < 4 && h < n) {
         st.unresolved_total += m;
         ++st.text_rounds;
-        uint32_t *vR = nullptr, m2 = 0;
         trace("before text round");
-        ARCHON_TRY(round_sort(1, m, h, cur, &vR));
-        trace("text round sort");
-        ARCHON_TRY(round_finish(true, m, cur, vR, &m2));
-        trace("text round finish");
-        cur ^= 1;
+        ARCHON_TRY(do_round(1, h));
+        trace("text round");
         h += 4;
+        const uint32_t m2 = ms + mb;
         const bool productive = (uint64_t)m2 * 2 <= m;
         m = m2;
         if (!productive) break;
@@ -355,39 +415,21 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     while (m) {
         st.unresolved_total += m;
         ++st.doubling_rounds;
-        uint32_t *vR = nullptr, m2 = 0;
 #ifdef ARCHON_EXPERIMENTS
-        if (getenv("ARCHON_TRACE_GROUPS")) {
-            unsigned long long *gh = reinterpret_cast<unsigned long long *>(B.scan_tmp);
-            ARCHON_HIP_TRY(hipMemsetAsync(gh, 0, 32 * sizeof(unsigned long long), s));
-            hipLaunchKernelGGL(fwd::k_group_hist, dim3(div_up(m, 256)), dim3(256), 0, s, B.ug[cur], m, gh);
-            unsigned long long hh[32];
-            ARCHON_HIP_TRY(hipMemcpyAsync(hh, gh, sizeof hh, hipMemcpyDeviceToHost, s));
-            ARCHON_HIP_TRY(hipStreamSynchronize(s));
-            fprintf(stderr, "groups h=%u:", h);
-            for (int b = 1; b < 32; ++b) if (hh[b]) fprintf(stderr, " 2^%d:%.1fM", b, hh[b] / 1e6);
-            fprintf(stderr, "\n");
-        }
-        const uint64_t big0 = st.seg_big_items;
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         const auto t0 = std::chrono::steady_clock::now();
+        const uint32_t ms0 = ms, mb0 = mb;
+        const uint64_t big0 = st.seg_big_items;
 #endif
-        ARCHON_TRY(round_sort(0, m, h, cur, &vR));
-#ifdef ARCHON_EXPERIMENTS
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
-        const auto t1 = std::chrono::steady_clock::now();
-#endif
-        ARCHON_TRY(round_finish(false, m, cur, vR, &m2));
+        ARCHON_TRY(do_round(0, h));
 #ifdef ARCHON_EXPERIMENTS
         if (getenv("ARCHON_TRACE_ROUNDS")) {
-            ARCHON_HIP_TRY(hipStreamSynchronize(s));
-            const auto t2 = std::chrono::steady_clock::now();
-            fprintf(stderr, "round h=%u m=%u big=%llu sort %.3f ms finish %.3f ms -> m2=%u\n", h, m, (unsigned long long)(st.seg_big_items - big0),
-                    std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(), m2);
+            const auto t1 = std::chrono::steady_clock::now();
+            fprintf(stderr, "round h=%u S=%u B=%u (sorted globally %llu) %.3f ms -> S=%u B=%u\n", h, ms0, mb0, (unsigned long long)(st.seg_big_items - big0),
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(), ms, mb);
         }
 #endif
-        cur ^= 1;
-        m = m2;
+        m = ms + mb;
         if (h > n && m) {   // h >= n resolves everything; reaching here means an internal fault
             set_error("doubling did not converge (m=%u at h=%u)", m, h);
             return ARCHON_E_INTERNAL;
@@ -444,7 +486,10 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     B.trash = c->alloc<uint4>((size_t)bs::kMaxRanges * bs::kTrashWords);
     B.h16part = c->alloc<uint32_t>((size_t)bs::kMaxRanges * 32768u);
     B.small = c->alloc<uint32_t>(1024);
-    if (!B.small) {
+    B.slist[0] = c->alloc<uint2>((size_t)n + 8);
+    B.slist[1] = c->alloc<uint2>((size_t)n + 8);
+    B.rlog = c->alloc<uint2>((size_t)n + 8);
+    if (!B.small || !B.rlog) {
         set_error("arena exhausted");
         return ARCHON_E_NOMEM;
     }
