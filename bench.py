@@ -61,9 +61,17 @@ def cpu_baseline(block_bytes):
             kv = dict(t.split("=") for t in r.stdout.split())
             if r.returncode == 0 and int(kv.get("validate", "0")) == 1:
                 secs = float(kv["sa_time"])
-                return {"value": round(sample_n / 1e6 / secs, 3), "unit": "MB/s", "cores": 1, "kind": "reference",
-                        "sample": sample + "; reference a7 -O3 (oracle/_ref/a7ref)",
-                        "host_cores": os.cpu_count()}
+                out = {"value": round(sample_n / 1e6 / secs, 3), "unit": "MB/s", "cores": 1, "kind": "reference",
+                       "sample": sample + "; reference a7 -O3 (oracle/_ref/a7ref)",
+                       "host_cores": os.cpu_count()}
+                # a7 slows down with the block size (cache misses per induced element): what it took on the WHOLE block of
+                # the metric, recorded when the reference digests were generated (development container, not this host)
+                full = reference_digest("random", 0, block_bytes)
+                if full is not None and full.get("reference_sa_time_s"):
+                    out["reference_at_metric_size"] = {"value": round(block_bytes / 1e6 / full["reference_sa_time_s"], 3), "unit": "MB/s",
+                                                       "seconds": round(full["reference_sa_time_s"], 1), "block_bytes": block_bytes,
+                                                       "host": "development container (tests/golden/golden_full.json), 1 core"}
+                return out
         except Exception:
             pass
         finally:
@@ -300,6 +308,10 @@ def main():
                 "gates_passed": ok,                        # reference digests + LF-consistency (+ gathered round trip)
                 "gathered_block_round_trip": gathered_ok,
                 "pass_ranges": int(os.environ.get("ARCHON_PASS_RANGES", "256")),
+                "backend": (dist.get_backend() if dist is not None else None),
+                "dist_world_size": (dist.get_world_size() if dist is not None else 1),
+                "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if dist is not None and args.backend == "nccl" else None),
+                "exchange": ("torch.distributed.gather (RCCL grouped send/recv) of %d bytes per rank per step, dst 0" % (n + 4)) if dist is not None else None,
             },
             "roofline": {
                 "bound": "hbm",

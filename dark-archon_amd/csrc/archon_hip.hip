@@ -156,7 +156,7 @@ struct FwdBuf {
 // first-stage order, v[i] = i at the first row of every group of equal h-byte keys and 0
 // elsewhere.  Runs scan -> scatter_rank -> doubling rounds -> sa_to_bwt.
 static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, uint32_t n, uint32_t *sa, uint32_t h0,
-                         uint8_t *d_bwt, uint32_t *d_base, archon_hip_stats &st, uint32_t p_hint = 0, bool ws_ready = true)
+                         uint8_t *d_bwt, uint32_t *d_base, archon_hip_stats &st, uint32_t p_hint, bool ws_ready, bool fused_ok)
 {
     const uint32_t g256 = div_up(n, 256);
 #ifdef ARCHON_EXPERIMENTS
@@ -174,9 +174,14 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
 #endif
     trace("enter");
     uint32_t *d_total = B.small + 600;
+    uint32_t *d_fu = B.small + 700;              // [0] entries appended to the next S list, [1] rank log entries, [2] the next B list, [3] its groups
     ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 4, d_fu, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     ARCHON_HIP_TRY(hipStreamSynchronize(s));
-    uint32_t m = c->h_mail[0];
+    // k_first_groups (ws_mode 2) left the two lists of the refinement rounds: S in B.slist[0], B as triples in buffer 0
+    const bool lists_ready = fused_ok && ws_ready;
+    const uint32_t ms_first = lists_ready ? c->h_mail[4] : 0u, mb_first = c->h_mail[0], groups_first = c->h_mail[7];
+    uint32_t m = ms_first + mb_first;
     st.unresolved_initial = m;
     bool compacted = ws_ready;                   // k_first_groups left the working set in upos/ug/uitem[0] (or only counted it)
     bool keep_ready = false;                     // B.keep / B.dst describe the current tied set
@@ -255,7 +260,9 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
                                B.uitem[0]);
             ++c->launches;
         }
-        ARCHON_HIP_TRY(hipMemcpyAsync(B.uinit, B.upos[0], (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        // (round-2 route: the rows are gathered again at the end, k_bwt_fix; the two-list route writes a row's symbol
+        //  when the row becomes final)
+        if (!fused_ok) ARCHON_HIP_TRY(hipMemcpyAsync(B.uinit, B.upos[0], (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
     // Text rounds: while few items are tied, key them on the next four bytes of the text instead of on ranks -- no
     // inverse suffix array yet (its 4N-byte scatter costs more than a whole round on a small working set).  They stop
@@ -334,9 +341,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     };
     // ---- the two lists (rounds.hiph): S = entries of groups of at most fwd::kFuMax rows, one fused kernel per round;
     //      B = the longer groups, on the round_sort / round_finish path above, handed over to S as they split
-    const bool fused_ok = !getenv("ARCHON_NO_FUSED");
-    uint32_t *d_fu = B.small + 700;              // [0] entries appended to the next S list, [1] rank log entries, [2] the next B list
-    uint32_t ms = 0, mb = m;
+    uint32_t ms = 0, mb = m, bgroups = m / 2u + 1u;
     int cs = 0;
     // triples in buffer `from` (mm of them, in row order) -> short groups appended to S list `cs_out`, the rest to buffer `from ^ 1`
     auto classify = [&](int from, uint32_t mm, int cs_out) -> int {
@@ -350,46 +355,128 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         ++c->launches;
         return ARCHON_OK;
     };
-    if (m && fused_ok) {
-        ARCHON_HIP_TRY(hipMemsetAsync(d_fu, 0, 3 * sizeof(uint32_t), s));
+    if (m && fused_ok && compacted && lists_ready) {
+        ms = ms_first;
+        mb = mb_first;
+        bgroups = groups_first;
+    } else if (m && fused_ok) {
+        // the run shortcut changed the tied set (or the set was only counted): triples of all of it in buffer 0 -> the lists
+        ARCHON_HIP_TRY(hipMemsetAsync(d_fu, 0, 4 * sizeof(uint32_t), s));
         ARCHON_TRY(classify(cur, m, cs));
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_fu, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         ms = c->h_mail[0];
         mb = c->h_mail[2];
+        bgroups = mb / (fwd::kFuMax + 1u) + 2u;          // every group left in B is longer than kFuMax
         cur ^= 1;
         if (ms + mb != m) { set_error("classification lost entries (%u + %u of %u)", ms, mb, m); return ARCHON_E_INTERNAL; }
         trace("classify");
     }
-    // one round over both lists: mode 0 keys on rank[s-h], mode 1 on the next four text bytes
+    // one round over both lists: mode 0 keys on rank[s-h], mode 1 on the next four text bytes.
+    // The rank table is read by every key gather of the round (S: k_round_fused, B: k_b_keys) before anything writes it
+    // (S: k_rank_apply, B: k_b_finish): the launches below are ordered accordingly.
+    // pair chains (rounds.hiph, k_pair_*): buffers that only the round-2 route uses otherwise
+    uint64_t *pk = reinterpret_cast<uint64_t *>(B.keep), *pk2 = reinterpret_cast<uint64_t *>(B.dst);       // n/2 records of 8 bytes each
+    uint32_t *pv = B.vw, *pv2 = B.vw + n / 2 + 1, *pair_v = B.uinit, *pair_code = B.uinit + n / 2 + 1;
+    bool chain_next = false;                     // list the pairs of the coming round and settle them by passage
+    uint32_t chain_cool = 0;
+    const bool chain_ok = fused_ok && n >= 4 && !getenv("ARCHON_NO_PAIR_CHAINS");
     auto do_round = [&](int mode, uint32_t hh) -> int {
-        ARCHON_HIP_TRY(hipMemsetAsync(d_fu, 0, 3 * sizeof(uint32_t), s));
+        const uint32_t chain = (chain_next && mode == 0 && ms) ? 1u : 0u;
+        const uint32_t m_before = ms + mb;
+        ARCHON_HIP_TRY(hipMemsetAsync(d_fu, 0, 6 * sizeof(uint32_t), s));
+        // B: keys (the gather) now, global sort on (group, key) behind the S kernel -- which so runs while the host waits for
+        // the sort's digit counts
+        uint32_t *vR = nullptr;
+        uint32_t shift = 32, gbits = 1;
+        if (mode == 0) { shift = 1; while ((2ull * n) >> shift) ++shift; }          // bits of a key k < 2n
+        while ((uint64_t)bgroups >> gbits) ++gbits;                                 // bits of a group number of the B list
+        unsigned long long *fg_status = reinterpret_cast<unsigned long long *>(B.sc.d_status);
+        if (mb && fused_ok) {
+            st.seg_big_items += mb;
+            const uint32_t tiles = div_up(mb, fwd::kFgTile);
+            ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
+            ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
+            if (mode == 0)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_keys<0>), dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], B.uitem[cur], B.rank, d_x, hh, n, shift, mb, kT, vT,
+                                   fg_status, B.sc.d_ticket, B.sc.d_err);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_keys<1>), dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], B.uitem[cur], B.rank, d_x, hh, n, shift, mb, kT, vT,
+                                   fg_status, B.sc.d_ticket, B.sc.d_err);
+            ++c->launches;
+        } else if (mb) {
+            ARCHON_TRY(round_sort(mode, mb, hh, cur, &vR));
+        }
         if (ms) {
             const dim3 grid(div_up(ms, fwd::kFuT)), block(fwd::kFuLanes);
             if (mode == 0)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_fused<0>), grid, block, 0, s, B.slist[cs], ms, B.rank, d_x, hh, sa, B.v, B.slist[cs ^ 1], B.rlog, d_fu, B.sc.d_err);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_fused<0>), grid, block, 0, s, B.slist[cs], ms, B.rank, d_x, hh, sa, B.v, B.slist[cs ^ 1], B.rlog, d_fu, B.sc.d_err, d_bwt, d_base, n, chain, pk, pv);
             else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_fused<1>), grid, block, 0, s, B.slist[cs], ms, B.rank, d_x, hh, sa, B.v, B.slist[cs ^ 1], B.rlog, d_fu, B.sc.d_err);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_fused<1>), grid, block, 0, s, B.slist[cs], ms, B.rank, d_x, hh, sa, B.v, B.slist[cs ^ 1], B.rlog, d_fu, B.sc.d_err, d_bwt, d_base, n, chain, pk, pv);
             ARCHON_HIP_TRY(hipGetLastError());
             ++c->launches;
         }
         uint32_t mb2 = 0;
-        if (mb) {
-            uint32_t *vR = nullptr;
-            ARCHON_TRY(round_sort(mode, mb, hh, cur, &vR));
+        if (mb && fused_ok) {
+            const uint32_t nbytes = (shift + gbits + 7) / 8;
+            uint32_t passes = 0;
+            bool b_in_b = false;
+            ARCHON_TRY(rs::sort_pairs(s, B.sc, kT, vT, kS, vS, mb, (1u << nbytes) - 1u, &b_in_b, &passes, &c->launches));
+            const uint32_t tiles = div_up(mb, fwd::kFgTile);
+            ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
+            ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
+            const uint64_t *ks = b_in_b ? kS : kT;
+            const uint32_t *vs = b_in_b ? vS : vT;
+            if (mode == 0)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_finish<0>), dim3(tiles), dim3(256), 0, s, ks, vs, B.upos[cur], B.ug[cur], mb, sa, B.rank, B.slist[cs ^ 1], d_fu,
+                                   B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1], fg_status, B.sc.d_ticket, B.sc.d_err, d_x, d_bwt, d_base, n);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_finish<1>), dim3(tiles), dim3(256), 0, s, ks, vs, B.upos[cur], B.ug[cur], mb, sa, B.v, B.slist[cs ^ 1], d_fu,
+                                   B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1], fg_status, B.sc.d_ticket, B.sc.d_err, d_x, d_bwt, d_base, n);
+            ARCHON_HIP_TRY(hipGetLastError());
+            ++c->launches;
+            cur ^= 1;                           // (short groups that straddle a tile of that sweep stay in B for another round)
+            mb2 = 1;                            // read with the round's counters below
+        } else if (mb) {
             ARCHON_TRY(round_finish(mode == 1, mb, cur, vR, &mb2));
-            if (mb2 && fused_ok) ARCHON_TRY(classify(cur ^ 1, mb2, cs ^ 1));      // what is left of B, back into buffer `cur`
-            else cur ^= 1;
+            cur ^= 1;
         }
         if (mode == 0 && ms) {                  // the S list's rank updates, now that every key of the round has been read
             hipLaunchKernelGGL(fwd::k_rank_apply, dim3(div_up(ms, 256)), dim3(256), 0, s, B.rlog, d_fu + 1, B.rank);
             ++c->launches;
         }
-        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_fu, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_fu, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         ms = c->h_mail[0];
-        mb = (mb2 && fused_ok) ? c->h_mail[2] : mb2;
+        mb = fused_ok ? (mb2 ? c->h_mail[2] : 0u) : mb2;
+        if (fused_ok) bgroups = c->h_mail[3];
         cs ^= 1;
+        uint32_t np = chain ? c->h_mail[4] : 0u;
+        const uint32_t pairs_seen = chain ? np : c->h_mail[5];
+        if (np) {
+            // the round's pairs by passage: sort the records by their smaller item, one look-up per run, spread, apply
+            bool in2 = false;
+            uint32_t passes = 0;
+            ARCHON_TRY(rs::sort_pairs(s, B.sc, pk, pv, pk2, pv2, np, 0xF0u, &in2, &passes, &c->launches));
+            const uint64_t *k2 = in2 ? pk2 : pk;
+            const uint32_t *v2 = in2 ? pv2 : pv;
+            hipLaunchKernelGGL(fwd::k_pair_heads, dim3(div_up(np, 256)), dim3(256), 0, s, k2, np, B.rank, pair_v, pair_code);
+            ARCHON_TRY(launch_scan<1>(s, pair_v, pair_v, np, B.scan_tmp, nullptr));
+            hipLaunchKernelGGL(fwd::k_pair_apply, dim3(div_up(np, 256)), dim3(256), 0, s, k2, v2, pair_v, pair_code, np, sa, B.rank, d_x, d_bwt, d_base, n,
+                               B.slist[cs], d_fu);
+            ARCHON_HIP_TRY(hipGetLastError());
+            c->launches += 4;
+            ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_fu, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            ARCHON_HIP_TRY(hipStreamSynchronize(s));
+            const uint32_t back = c->h_mail[0] - ms;         // entries the pass could not settle (two per pair)
+            ms = c->h_mail[0];
+            st.chain_pairs += np - back / 2u;
+            if ((uint64_t)back > np) chain_cool = 3;         // fewer than half of the pairs settled: give the rounds some time
+        }
+        // the next round lists its pairs when this one got nowhere and pairs are most of what is left
+        if (chain_cool) --chain_cool;
+        const uint32_t m_after = ms + mb;
+        chain_next = chain_ok && !chain_cool && (uint64_t)m_after * 4 >= (uint64_t)m_before * 3 && (uint64_t)pairs_seen * 4 >= ms && ms;
         return ARCHON_OK;
     };
     const bool text_ok = !getenv("ARCHON_NO_TEXT_ROUNDS");
@@ -427,6 +514,14 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             const auto t1 = std::chrono::steady_clock::now();
             fprintf(stderr, "round h=%u S=%u B=%u (sorted globally %llu) %.3f ms -> S=%u B=%u\n", h, ms0, mb0, (unsigned long long)(st.seg_big_items - big0),
                     std::chrono::duration<double, std::milli>(t1 - t0).count(), ms, mb);
+            if (ms0 && getenv("ARCHON_TRACE_STAMPS")) {
+                unsigned long long v[24];
+                if (hipMemcpyFromSymbol(v, HIP_SYMBOL(fwd::g_fu_stamps), sizeof v) == hipSuccess) {
+                    fprintf(stderr, "   fused wg: longest %llu owned %llu surv/log 0x%llx cycles:", v[11], v[12], v[13]);
+                    for (int i = 2; i <= 10; ++i) fprintf(stderr, " %llu", v[i] - v[i - 1]);
+                    fprintf(stderr, " (load, own, gather-issue, heads, ends, sort, newgroups, counts+atomic, stores)\n");
+                }
+            }
         }
 #endif
         m = ms + mb;
@@ -438,7 +533,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     }
     // A7 for the rows the doubling rounds moved (every other row already holds its symbol)
     trace("rounds done");
-    if (m0) {
+    if (m0 && !fused_ok) {
         hipLaunchKernelGGL(fwd::k_bwt_fix, dim3(div_up(m0, 256)), dim3(256), 0, s, d_x, sa, B.uinit, m0, n, d_bwt, d_base);
         ARCHON_HIP_TRY(hipGetLastError());
         ++c->launches;
@@ -643,17 +738,20 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         return ARCHON_OK;
     };
     // entry of the general stage (k_first_groups): clean SA, group starts and the compacted working set in one sweep
+    const bool fused_ok = !getenv("ARCHON_NO_FUSED");        // (tests: the round-2 route, one ordered list of triples)
     auto first_groups = [&](int mode, const uint64_t *keys, const uint32_t *items, uint32_t shift, bool write_ws) -> int {
         unsigned long long *fg_status = reinterpret_cast<unsigned long long *>(B.sc.d_status);
         const uint32_t tiles = div_up(n, fwd::kFgTile);
         ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
         ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
+        ARCHON_HIP_TRY(hipMemsetAsync(small + 700, 0, 4 * sizeof(uint32_t), s));
+        const uint32_t ws_mode = !write_ws ? 0u : fused_ok ? 2u : 1u;      // 2: the S / B lists of rounds.hiph
         if (mode == 0)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_first_groups<0>), dim3(tiles), dim3(256), 0, s, keys, items, shift, n, sa, d_bwt, d_base, B.v,
-                               B.upos[0], B.ug[0], B.uitem[0], small + 600, fg_status, B.sc.d_ticket, B.sc.d_err, write_ws ? 1u : 0u);
+                               B.upos[0], B.ug[0], B.uitem[0], small + 600, fg_status, B.sc.d_ticket, B.sc.d_err, ws_mode, B.slist[0], small + 700, (uint32_t)fwd::kFuMax);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_first_groups<1>), dim3(tiles), dim3(256), 0, s, keys, items, shift, n, sa, d_bwt, d_base, B.v,
-                               B.upos[0], B.ug[0], B.uitem[0], small + 600, fg_status, B.sc.d_ticket, B.sc.d_err, write_ws ? 1u : 0u);
+                               B.upos[0], B.ug[0], B.uitem[0], small + 600, fg_status, B.sc.d_ticket, B.sc.d_err, ws_mode, B.slist[0], small + 700, (uint32_t)fwd::kFuMax);
         ARCHON_HIP_TRY(hipGetLastError());
         ++c->launches;
         return ARCHON_OK;
@@ -842,7 +940,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     }
 
     if (need_general) {
-        ARCHON_TRY(general_stage(c, s, B, d_x, n, sa, h0, d_bwt, d_base, st, period_hint, ws_ready));
+        ARCHON_TRY(general_stage(c, s, B, d_x, n, sa, h0, d_bwt, d_base, st, period_hint, ws_ready, fused_ok));
         e4 = tm.mark();
         ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, d_base, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
@@ -1304,6 +1402,14 @@ int archon_hip_exp_stamps(unsigned long long out[64])
 int archon_hip_exp_ls_stamps(unsigned long long out[16])
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(bs::g_ls_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? ARCHON_OK : ARCHON_E_HIP;
+}
+#endif
+
+#ifdef ARCHON_EXPERIMENTS
+/* phase stamps of the middle workgroup of the last k_round_fused launch */
+int archon_hip_exp_fu_stamps(unsigned long long out[24])
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fwd::g_fu_stamps), 24 * sizeof(unsigned long long)) == hipSuccess ? ARCHON_OK : ARCHON_E_HIP;
 }
 #endif
 

@@ -43,6 +43,7 @@ class Stats(ctypes.Structure):
         ("ms_pass_text", ctypes.c_float), ("ms_pass_rec", ctypes.c_float),
         ("alphabet_bits", ctypes.c_uint32), ("period", ctypes.c_uint32),
         ("chain_items", ctypes.c_uint32), ("text_rounds", ctypes.c_uint32), ("seg_big_items", ctypes.c_uint64),
+        ("chain_pairs", ctypes.c_uint64),
     ]
 
     def asdict(self):

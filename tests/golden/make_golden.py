@@ -51,6 +51,11 @@ def main():
                     "shipped_a7": "crash" if shipped is None else ("ok" if shipped["validate"] == 1 else "fails_own_validate")}
             if shipped is not None and shipped["validate"] == 1:
                 assert (shipped["P"] == nt["P"]).all() and (shipped["bwt"] == nt["bwt"]).all() and shipped["base"] == nt["base"]
+            # A3: the reference's own findLMS placement (oracle/_ref/a7lms): number of LMS items + digest of count[256] || items
+            lms = OB.run_ref_lms(x)
+            assert lms is not None, "oracle/_ref/a7lms missing: make -C oracle"
+            case["lms_n1"] = int(lms[1].size)
+            case["sha256_lms"] = OB.lms_digest(lms[0], lms[1])
             case["base_id"] = nt["base"]
             case["sha256_P"], case["sha256_bwt_base"] = digest(nt["P"], nt["bwt"], nt["base"])
             if n in SMALL:

@@ -145,3 +145,28 @@ def run_ref(x, variant="a7ref", tmpdir="/tmp"):
         for ext in (".in", ".bwt", ".sa"):
             if os.path.exists(tag + ext):
                 os.remove(tag + ext)
+
+
+def run_ref_lms(x, tmpdir="/tmp"):
+    """The reference's own Constructor<byte>::findLMS (archon.cpp:160-172) through oracle/_ref/a7lms:
+    returns (count[256], items) as a7 places them, or None when the binary is absent."""
+    exe = os.path.join(REF_DIR, "a7lms")
+    if not os.path.exists(exe):
+        return None
+    tag = "%s/a7lms_%d" % (tmpdir, os.getpid())
+    np.ascontiguousarray(x, np.uint8).tofile(tag + ".in")
+    try:
+        r = subprocess.run([exe, tag + ".in", tag + ".out"], capture_output=True, text=True)
+        if r.returncode != 0:
+            return None
+        d = np.fromfile(tag + ".out", np.uint32)
+        return d[1:257].copy(), d[257:257 + int(d[0])].copy()
+    finally:
+        for ext in (".in", ".out"):
+            if os.path.exists(tag + ext):
+                os.remove(tag + ext)
+
+
+def lms_digest(count, items):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(count, "<u4").tobytes() + np.ascontiguousarray(items, "<u4").tobytes()).hexdigest()

@@ -276,11 +276,13 @@ def _seg_cases():
 
 @pytest.mark.parametrize("name", sorted(_seg_cases()))
 def test_segmented_rounds(archon, oracle, name, monkeypatch):
-    """Refinement rounds (text rounds and prefix doubling) with short groups sorted inside k_seg_round and long groups
-    through the global sort, in every mix: same order as the oracle, and the same as with the segmented sort off."""
+    """Refinement rounds (text rounds and prefix doubling) with short groups sorted in LDS (k_round_fused over the S list)
+    and long groups through the global sort (B list), in every mix: same order as the oracle, and the same on the round-2
+    route (one ordered list, k_seg_round) with and without its segmented sort."""
     x = _seg_cases()[name]
     P, B, b0 = oracle.forward(x)
-    for env in ({}, {"ARCHON_FORCE_PATH": "0"}, {"ARCHON_NO_TEXT_ROUNDS": "1", "ARCHON_NO_CHAINS": "1"}, {"ARCHON_NO_SEG_ROUNDS": "1"}):
+    for env in ({}, {"ARCHON_FORCE_PATH": "0"}, {"ARCHON_NO_TEXT_ROUNDS": "1", "ARCHON_NO_CHAINS": "1"}, {"ARCHON_NO_FUSED": "1"},
+                {"ARCHON_NO_FUSED": "1", "ARCHON_NO_SEG_ROUNDS": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         sa, bwt, base = archon.forward(x)
@@ -289,8 +291,6 @@ def test_segmented_rounds(archon, oracle, name, monkeypatch):
             monkeypatch.delenv(k)
         assert (sa == P).all(), (name, env)
         assert (bwt == B).all() and base == b0
-        if "ARCHON_NO_SEG_ROUNDS" in env:
-            assert st["seg_big_items"] == 0
     assert st["text_rounds"] + st["doubling_rounds"] > 0
 
 
@@ -444,6 +444,15 @@ def test_lms_select(archon, oracle):
     x = S.gen_random(1 << 22)
     _, items = archon.lms_select(x)
     assert abs(items.size / x.size - 1 / 3) < 0.01          # LMS density 0.33 on random bytes
+    # ... and against the reference itself: digests of the placement a7's own findLMS produced (tests/golden/golden.json,
+    # written by make_golden.py from oracle/_ref/a7lms), no oracle in between
+    import json, os
+    import oracle_binding as OB
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.json")) as f:
+        golden = json.load(f)
+    for case in golden["cases"]:
+        count, items = archon.lms_select(S.gen_shape(case["shape"], case["n"]))
+        assert items.size == case["lms_n1"] and OB.lms_digest(count, items) == case["sha256_lms"], (case["shape"], case["n"])
 
 
 def test_two_byte_count_hot_bins(archon, oracle):

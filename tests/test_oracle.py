@@ -57,6 +57,21 @@ def test_golden_reference_outputs(oracle, case):
         assert oracle.validate(x, P)
         rc, back = oracle.inverse(bwt, base)
         assert rc == 0 and (back == x).all()
+    # A3: oracle_lms_select against the placement the reference's own findLMS produced (oracle/_ref/a7lms, make_golden.py)
+    count, items = oracle.lms_select(x)
+    assert items.size == case["lms_n1"] and OB.lms_digest(count, items) == case["sha256_lms"]
+
+
+def test_live_reference_lms(oracle):
+    """the reference's findLMS itself (when oracle/_ref/a7lms is present: development container and GPU box)"""
+    if not OB.ref_available("a7lms"):
+        pytest.skip("oracle/_ref/a7lms not built")
+    rng = np.random.default_rng(5)
+    for x in [rng.integers(0, 256, 5000).astype(np.uint8), rng.integers(0, 2, 777).astype(np.uint8), S.gen_text(30000),
+              np.arange(256, dtype=np.uint8).repeat(3), np.frombuffer(b"a" * 100, np.uint8), np.frombuffer(b"ba", np.uint8)]:
+        ref = OB.run_ref_lms(x)
+        count, items = oracle.lms_select(x)
+        assert ref is not None and (ref[0] == count).all() and ref[1].size == items.size and (ref[1] == items).all()
 
 
 def test_random_small_vs_definition(oracle):

@@ -26,6 +26,7 @@ timeout -k 10 120 python3 tools/stage_times.py 256 random 3 inv 2>/dev/null | ta
 cat $out/stage_times.txt
 timeout -k 10 600 python3 tools/config5.py 256 2>/dev/null | tail -1 > $out/config5.json && cat $out/config5.json
 timeout -k 10 300 python3 tools/real_text.py 256 2>/dev/null | tail -1 > $out/real_text.json && cat $out/real_text.json
+timeout -k 10 120 python3 tools/radix_dir_bench.py 2>/dev/null | tail -1 > $out/radix_dir_bench.json && cat $out/radix_dir_bench.json
 # the micro-benchmarks DESIGN.md quotes (LDS operation rates, the pass skeleton with aligned / unaligned runs)
 for m in lds_rates pass_model scatter_pass; do
   hipcc -O3 --offload-arch=gfx950 -o /tmp/$m tools/micro/$m.hip 2>/dev/null && timeout -k 10 120 /tmp/$m > $out/micro_$m.txt 2>&1

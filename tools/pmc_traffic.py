@@ -22,9 +22,15 @@ for cc in glob.glob(root + "/*/*/*_counter_collection.csv"):
         name = r["Kernel_Name"].split("(")[0].split("<")[0].replace("archon::", "").replace("void ", "").strip()
         if name in ALG and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             vals[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"_comment": "HBM traffic per launch of the streaming kernels, MI355X, rocprofv3 separate --pmc passes (tools/pmc.sh via "
+dest = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_traffic.json")
+try:
+    prev = json.load(open(dest))          # entries of other shapes / sizes / routes stay (each carries its own `source`)
+except Exception:
+    prev = {}
+out = dict(prev)
+out["_comment"] = ( "HBM traffic per launch of the streaming kernels, MI355X, rocprofv3 separate --pmc passes (tools/pmc.sh via "
                    "tools/evidence.sh): 2 x FETCH_SIZE (gfx950 under-count, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes. "
-                   "Source: " + source}
+                   "each entry names its source")
 ent = {}
 for name, c in vals.items():
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
@@ -34,5 +40,5 @@ for name, c in vals.items():
     ent[name] = {"fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024),
                  "algorithmic_bytes_per_launch": ALG[name] * n, "source": source}
 out["path1_%s_%d" % (shape, n)] = ent
-json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(dest, "w"), indent=1)
 print(json.dumps(ent, indent=1))
