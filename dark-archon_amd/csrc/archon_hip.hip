@@ -6,6 +6,7 @@
 #include "bucket_sort.hiph"
 #include "forward.hiph"
 #include "rounds.hiph"
+#include "rank_writer.hiph"
 #include "inverse.hiph"
 
 #include <stdarg.h>
@@ -134,6 +135,8 @@ static size_t forward_arena_bytes(uint32_t n)
     add(4 * (size_t)bs::kMaxRanges * 32768u);     // partial two-byte counts
     add(4 * 1024);                            // counts, starts, ticket, err, base, totals, TieCtl
     add(8 * N + 64); add(8 * N + 64); add(8 * N + 64);      // the S lists of the refinement rounds (double-buffered) and the rank log
+    add(8 * rw::region_records(n)); add(8 * rw::region_records(n));     // rank_writer.hiph: records by coarse / fine bucket
+    add(4 * (rw::kMaxCoarse + rw::fine_buckets(n) + 64));
     return b + 4096;
 }
 
@@ -143,6 +146,7 @@ struct FwdBuf {
     uint32_t *valA, *valB, *rank, *sa_own, *v, *keep, *dst;
     uint32_t *upos[2], *ug[2], *uitem[2], *uinit, *rhist, *vw;
     uint8_t *y;
+    rw::Buffers rwb;           // rank_writer.hiph
     uint2 *slist[2], *rlog;    // rounds.hiph: entries of short groups {row, item | head}, the round's rank updates {item, rank}
     uint32_t *scan_tmp, *hist16, *small;
     bs::Prep *prep;
@@ -383,6 +387,8 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     const bool chain_ok = fused_ok && n >= 4 && !getenv("ARCHON_NO_PAIR_CHAINS");
     auto do_round = [&](int mode, uint32_t hh) -> int {
         const uint32_t chain = (chain_next && mode == 0 && ms) ? 1u : 0u;
+        // many rank updates: dealt by item into windows of the table (rank_writer.hiph) instead of one random store each
+        const bool writer = mode == 0 && fused_ok && n >= (1u << 22) && (uint64_t)ms + mb >= (8u << 20) && !getenv("ARCHON_NO_RANK_WRITER");
         const uint32_t m_before = ms + mb;
         ARCHON_HIP_TRY(hipMemsetAsync(d_fu, 0, 6 * sizeof(uint32_t), s));
         // B: keys (the gather) now, global sort on (group, key) behind the S kernel -- which so runs while the host waits for
@@ -417,6 +423,8 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             ++c->launches;
         }
         uint32_t mb2 = 0;
+        uint2 *b_log = nullptr;
+        const uint32_t mb_round = mb;
         if (mb && fused_ok) {
             const uint32_t nbytes = (shift + gbits + 7) / 8;
             uint32_t passes = 0;
@@ -427,12 +435,13 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
             const uint64_t *ks = b_in_b ? kS : kT;
             const uint32_t *vs = b_in_b ? vS : vT;
+            b_log = writer ? reinterpret_cast<uint2 *>(b_in_b ? kT : kS) : nullptr;        // the sort's other key buffer is free now
             if (mode == 0)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_finish<0>), dim3(tiles), dim3(256), 0, s, ks, vs, B.upos[cur], B.ug[cur], mb, sa, B.rank, B.slist[cs ^ 1], d_fu,
-                                   B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1], fg_status, B.sc.d_ticket, B.sc.d_err, d_x, d_bwt, d_base, n);
+                                   B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1], fg_status, B.sc.d_ticket, B.sc.d_err, d_x, d_bwt, d_base, n, b_log);
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_finish<1>), dim3(tiles), dim3(256), 0, s, ks, vs, B.upos[cur], B.ug[cur], mb, sa, B.v, B.slist[cs ^ 1], d_fu,
-                                   B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1], fg_status, B.sc.d_ticket, B.sc.d_err, d_x, d_bwt, d_base, n);
+                                   B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1], fg_status, B.sc.d_ticket, B.sc.d_err, d_x, d_bwt, d_base, n, b_log);
             ARCHON_HIP_TRY(hipGetLastError());
             ++c->launches;
             cur ^= 1;                           // (short groups that straddle a tile of that sweep stay in B for another round)
@@ -441,7 +450,13 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             ARCHON_TRY(round_finish(mode == 1, mb, cur, vR, &mb2));
             cur ^= 1;
         }
-        if (mode == 0 && ms) {                  // the S list's rank updates, now that every key of the round has been read
+        if (writer) {                           // the round's rank updates (S: the log; B: k_b_finish's), now that every key has been read
+            ARCHON_HIP_TRY(hipMemsetAsync(B.rwb.cnt1, 0, (rw::kMaxCoarse + rw::fine_buckets(n)) * sizeof(uint32_t), s));
+            if (ms) hipLaunchKernelGGL(HIP_KERNEL_NAME(rw::k_part<1, 0>), dim3(div_up(ms, rw::kTile)), dim3(rw::kLanes), 0, s, B.rlog, d_fu + 1, 0u, nullptr, nullptr, nullptr, B.rwb.r1, B.rwb.cnt1);
+            if (b_log) hipLaunchKernelGGL(HIP_KERNEL_NAME(rw::k_part<1, 0>), dim3(div_up(mb_round, rw::kTile)), dim3(rw::kLanes), 0, s, b_log, nullptr, mb_round, nullptr, nullptr, nullptr, B.rwb.r1, B.rwb.cnt1);
+            ARCHON_TRY(rw::write_back(s, B.rwb, n, B.rank, &c->launches));
+            c->launches += 2;
+        } else if (mode == 0 && ms) {           // the S list's rank updates, now that every key of the round has been read
             hipLaunchKernelGGL(fwd::k_rank_apply, dim3(div_up(ms, 256)), dim3(256), 0, s, B.rlog, d_fu + 1, B.rank);
             ++c->launches;
         }
@@ -495,7 +510,14 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     if (m) {
         // ranks are needed only now (4N random stores): every item, not just the tied ones
         trace("before scatter_rank");
-        hipLaunchKernelGGL(fwd::k_scatter_rank, dim3(g256), dim3(256), 0, s, sa, B.v, n, B.rank);
+        if (n >= (1u << 22) && !getenv("ARCHON_NO_RANK_WRITER")) {
+            // rank[sa[i]] = gstart[i] dealt by item into windows of the table (rank_writer.hiph) instead of n random stores
+            ARCHON_HIP_TRY(hipMemsetAsync(B.rwb.cnt1, 0, (rw::kMaxCoarse + rw::fine_buckets(n)) * sizeof(uint32_t), s));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(rw::k_part<1, 1>), dim3(div_up(n, rw::kTile)), dim3(rw::kLanes), 0, s, nullptr, nullptr, n, sa, B.v, nullptr, B.rwb.r1, B.rwb.cnt1);
+            ARCHON_TRY(rw::write_back(s, B.rwb, n, B.rank, &c->launches));
+        } else {
+            hipLaunchKernelGGL(fwd::k_scatter_rank, dim3(g256), dim3(256), 0, s, sa, B.v, n, B.rank);
+        }
         ++c->launches;
         trace("scatter_rank");
     }
@@ -584,7 +606,11 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     B.slist[0] = c->alloc<uint2>((size_t)n + 8);
     B.slist[1] = c->alloc<uint2>((size_t)n + 8);
     B.rlog = c->alloc<uint2>((size_t)n + 8);
-    if (!B.small || !B.rlog) {
+    B.rwb.r1 = c->alloc<uint2>(rw::region_records(n));
+    B.rwb.r2 = c->alloc<uint2>(rw::region_records(n));
+    B.rwb.cnt1 = c->alloc<uint32_t>(rw::kMaxCoarse + rw::fine_buckets(n) + 64);
+    B.rwb.cnt2 = B.rwb.cnt1 + rw::kMaxCoarse;
+    if (!B.small || !B.rlog || !B.rwb.cnt1) {
         set_error("arena exhausted");
         return ARCHON_E_NOMEM;
     }
