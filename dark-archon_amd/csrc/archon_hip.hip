@@ -403,12 +403,14 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             const uint32_t tiles = div_up(mb, fwd::kFgTile);
             ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
             ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
+            ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ghist, 0, 8 * 256 * sizeof(uint32_t), s));
+            const uint32_t nbytes = (shift + gbits + 7) / 8;
             if (mode == 0)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_keys<0>), dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], B.uitem[cur], B.rank, d_x, hh, n, shift, mb, kT, vT,
-                                   fg_status, B.sc.d_ticket, B.sc.d_err);
+                                   fg_status, B.sc.d_ticket, B.sc.d_err, B.sc.d_ghist, nbytes);
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_keys<1>), dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], B.uitem[cur], B.rank, d_x, hh, n, shift, mb, kT, vT,
-                                   fg_status, B.sc.d_ticket, B.sc.d_err);
+                                   fg_status, B.sc.d_ticket, B.sc.d_err, B.sc.d_ghist, nbytes);
             ++c->launches;
         } else if (mb) {
             ARCHON_TRY(round_sort(mode, mb, hh, cur, &vR));
@@ -429,7 +431,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             const uint32_t nbytes = (shift + gbits + 7) / 8;
             uint32_t passes = 0;
             bool b_in_b = false;
-            ARCHON_TRY(rs::sort_pairs(s, B.sc, kT, vT, kS, vS, mb, (1u << nbytes) - 1u, &b_in_b, &passes, &c->launches));
+            ARCHON_TRY(rs::sort_pairs(s, B.sc, kT, vT, kS, vS, mb, (1u << nbytes) - 1u, &b_in_b, &passes, &c->launches, nullptr, nullptr, nullptr, true));
             const uint32_t tiles = div_up(mb, fwd::kFgTile);
             ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
             ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));

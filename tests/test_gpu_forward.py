@@ -529,3 +529,60 @@ def test_tie_heavy_block_full_size(archon):
     out_t = torch.empty(n, dtype=torch.uint8, device="cuda")
     archon.inverse_dev(bwt_t, int(base_t.item()), out_t)
     assert torch.equal(out_t, x_t)
+
+
+def _dup_cases():
+    rng = np.random.default_rng(91)
+    r = lambda k, hi=256: rng.integers(0, hi, size=k, dtype=np.uint8)
+    R = r(1 << 20)
+    words = [bytes(r(int(k), 26) + 97) for k in rng.integers(2, 9, size=400)]
+    prose = np.frombuffer(b" ".join(words[i] for i in rng.integers(0, 400, size=200000)), np.uint8)
+    return {
+        # random block with one long duplicate: every tied group is a pair {s, s + d} of ONE passage
+        "one_duplicate": np.concatenate([R, r(11), R[100000:900000], r(5)]),
+        # three copies of a passage (groups of three at first, pairs once the copies' left contexts differ), nested copies
+        "three_copies": np.concatenate([R[:300000], r(3), R[:300000], r(7), R[:200000], R[50000:250000]]),
+        # text with copied passages next to many short repeats: pairs are listed while longer groups keep doubling
+        "prose_with_copies": np.concatenate([prose[:400000], prose[100000:350000], prose[400000:600000], prose[120000:300000]]),
+        # a duplicate whose predecessors sit in a LONGER group (the run's head cannot be settled at first): 0-runs in front of the copies
+        "duplicate_behind_runs": np.concatenate([np.zeros(5000, np.uint8), R[:200000], np.zeros(5000, np.uint8), R[:200000], np.zeros(4000, np.uint8), R[:100000]]),
+    }
+
+
+@pytest.mark.parametrize("name", sorted(_dup_cases()))
+def test_pair_chains(archon, oracle, name, monkeypatch):
+    """Long duplicates (a4's anchors, bwt/a4/src/direct.c:90-161): the pairs of a repeated passage are listed, sorted by item
+    and settled passage by passage (k_pair_heads / k_pair_apply) -- same order as the oracle, with and without the shortcut
+    and with the run shortcut of the periodic blocks out of the way."""
+    x = _dup_cases()[name]
+    P, B, b0 = oracle.forward(x)
+    used = 0
+    for env in ({}, {"ARCHON_NO_CHAINS": "1"}, {"ARCHON_NO_CHAINS": "1", "ARCHON_FORCE_PATH": "0"}, {"ARCHON_NO_PAIR_CHAINS": "1", "ARCHON_NO_CHAINS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sa, bwt, base = archon.forward(x)
+        st = archon.stats()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert (sa == P).all(), (name, env)
+        assert (bwt == B).all() and base == b0, (name, env)
+        if "ARCHON_NO_PAIR_CHAINS" in env:
+            assert st["chain_pairs"] == 0
+        else:
+            used += st["chain_pairs"]
+    if name == "one_duplicate":
+        assert used > 0          # the passage was settled as pairs on at least one route
+
+
+def test_rank_writer_matches_direct_stores(archon, monkeypatch):
+    """rank updates dealt by item into windows of the table (rank_writer.hiph) against one store per update: the same
+    suffix array, on a block that keeps the writer busy for several rounds (the reference digest of prose-16Mi is in
+    golden.json; here the two routes are compared directly)."""
+    x = S.gen_shape("prose", 1 << 24)
+    sa1, bwt1, base1 = archon.forward(x)
+    assert archon.stats()["doubling_rounds"] > 4
+    monkeypatch.setenv("ARCHON_NO_RANK_WRITER", "1")
+    sa2, bwt2, base2 = archon.forward(x)
+    monkeypatch.delenv("ARCHON_NO_RANK_WRITER")
+    assert (sa1 == sa2).all() and (bwt1 == bwt2).all() and base1 == base2
+    assert archon.validate(x, sa1)

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 tag=$1; mib=${2:-256}
 if [ "$tag" = real ]; then prog="tools/real_text.py $mib"; else prog="tools/stage_times.py $mib $tag 3"; fi
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 $prog > gpurun_out/prof_$tag.log 2>&1
+rm -rf gpurun_out/prof_$tag; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 $prog > gpurun_out/prof_$tag.log 2>&1
 python3 - "$tag" <<'PY'
 import csv,glob,sys
 tag=sys.argv[1]
