@@ -27,6 +27,8 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+Route g_route;
+
 // ------------------------------------------------------------------ contexts
 static constexpr int kMaxDev = 64;
 static constexpr uint32_t kTieListCap = 1u << 20;
@@ -111,6 +113,13 @@ int ctx_io(Ctx *c, int slot, size_t bytes, void **out)
 }
 
 // ------------------------------------------------------------------ forward driver
+// Device arena of one forward call (one hipMalloc per device, bump-allocated).  Lifetimes decide what shares memory:
+//   keyA / keyB (8N each), the value block (8N)   first stage (pass records, or the (key, item) pairs of the 7-pass sort);
+//        then the B rounds' (group | key, item) pairs, k_b_finish's rank log in the key buffer the sort left free, and --
+//        between rounds, when all of that is dead -- the rank writer's two record regions and the pair chains' sort buffers
+//   rlog (8N)   the S rounds' rank log; before the rounds: scratch of the run shortcut / the scans (B.dst)
+//   keep (4N)   scratch of the run shortcut and the recount; in the rounds: the pair list
+static size_t key_words(uint32_t n) { const size_t r = rw::region_records(n); return r > (size_t)n + 8 ? r : (size_t)n + 8; }      // u64 words of a key buffer
 static size_t forward_arena_bytes(uint32_t n)
 {
     const size_t N = n;
@@ -118,12 +127,13 @@ static size_t forward_arena_bytes(uint32_t n)
     auto add = [&](size_t bytes) { b += (bytes + 255) & ~size_t(255); };
     add(N + 64);                    // aligned copy of x (when needed)
     add(N + 64);                    // packed key text y (compacted alphabets)
-    add(8 * N + 64); add(8 * N + 64);   // keyA keyB  (fast path: K,I of pass A / pass B)
-    add(4 * N + 64); add(4 * N + 64);   // valA valB  (fast path: CB of pass A, C of pass B)
+    add(8 * key_words(n)); add(8 * key_words(n));       // keyA keyB
+    add(8 * key_words(n));          // valA | valB
     add(4 * (N + 1));               // rank
     add(4 * N);                     // sa (when the caller wants none)
-    add(4 * N); add(4 * N); add(4 * N);       // v / gstart, keep, dst
-    for (int i = 0; i < 8; ++i) add(4 * N);   // upos, ug, uitem (double-buffered), the initial rows, the round's group starts
+    add(4 * N); add(4 * N);         // v / gstart, keep
+    for (int i = 0; i < 6; ++i) add(4 * N);   // upos, ug, uitem (double-buffered): the B list
+    add(4 * (N / 2 + 8));           // the pair list's {row, flag} words
     add(4 * scan_temp_words(N));
     add(4 * rs::status_words(n));
     add(4 * 8 * 256); add(4 * 8 * 256);       // ghist, gstart
@@ -135,7 +145,6 @@ static size_t forward_arena_bytes(uint32_t n)
     add(4 * (size_t)bs::kMaxRanges * 32768u);     // partial two-byte counts
     add(4 * 1024);                            // counts, starts, ticket, err, base, totals, TieCtl
     add(8 * N + 64); add(8 * N + 64); add(8 * N + 64);      // the S lists of the refinement rounds (double-buffered) and the rank log
-    add(8 * rw::region_records(n)); add(8 * rw::region_records(n));     // rank_writer.hiph: records by coarse / fine bucket
     add(4 * (rw::kMaxCoarse + rw::fine_buckets(n) + 64));
     return b + 4096;
 }
@@ -144,9 +153,9 @@ struct FwdBuf {
     uint8_t *xa;
     uint64_t *keyA, *keyB;
     uint32_t *valA, *valB, *rank, *sa_own, *v, *keep, *dst;
-    uint32_t *upos[2], *ug[2], *uitem[2], *uinit, *rhist, *vw;
+    uint32_t *upos[2], *ug[2], *uitem[2], *rhist, *pairw;
     uint8_t *y;
-    rw::Buffers rwb;           // rank_writer.hiph
+    rw::Buffers rwb;           // rank_writer.hiph (r1 / r2 are set per use: they live in the key / value buffers)
     uint2 *slist[2], *rlog;    // rounds.hiph: entries of short groups {row, item | head}, the round's rank updates {item, rank}
     uint32_t *scan_tmp, *hist16, *small;
     bs::Prep *prep;
@@ -156,11 +165,14 @@ struct FwdBuf {
     rs::Scratch sc;
 };
 
-// A5 + A7 for whatever the first stage left tied.  On entry: sa[] holds the items in
-// first-stage order, v[i] = i at the first row of every group of equal h-byte keys and 0
-// elsewhere.  Runs scan -> scatter_rank -> doubling rounds -> sa_to_bwt.
+// A5 + A7 for whatever the first stage left tied.  On entry (k_first_groups): sa[] holds the items in first-stage order,
+// B.v[i] = first row of the group of row i, and -- ws_ready -- the two lists of the refinement rounds (rounds.hiph): S =
+// entries of groups of at most fwd::kFuMax rows in B.slist[0] (small + 700 counts them), B = the longer groups as
+// (row, group start, item) triples in buffer 0 (small + 600 counts them, small + 703 their groups).  Runs the run
+// shortcut for periodic blocks, text rounds, the rank table, doubling rounds with the pair chains.  Rows take their
+// BWT symbol when they become final.
 static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, uint32_t n, uint32_t *sa, uint32_t h0,
-                         uint8_t *d_bwt, uint32_t *d_base, archon_hip_stats &st, uint32_t p_hint, bool ws_ready, bool fused_ok)
+                         uint8_t *d_bwt, uint32_t *d_base, archon_hip_stats &st, uint32_t p_hint, bool ws_ready, bool deep_ties)
 {
     const uint32_t g256 = div_up(n, 256);
 #ifdef ARCHON_EXPERIMENTS
@@ -178,25 +190,24 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
 #endif
     trace("enter");
     uint32_t *d_total = B.small + 600;
-    uint32_t *d_fu = B.small + 700;              // [0] entries appended to the next S list, [1] rank log entries, [2] the next B list, [3] its groups
+    uint32_t *d_fu = B.small + 700;              // [0] entries appended to the next S list, [1] rank log entries, [2] the next B list, [3] its groups, [4] pairs listed, [5] pairs seen
     ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 4, d_fu, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     ARCHON_HIP_TRY(hipStreamSynchronize(s));
-    // k_first_groups (ws_mode 2) left the two lists of the refinement rounds: S in B.slist[0], B as triples in buffer 0
-    const bool lists_ready = fused_ok && ws_ready;
-    const uint32_t ms_first = lists_ready ? c->h_mail[4] : 0u, mb_first = c->h_mail[0], groups_first = c->h_mail[7];
+    const uint32_t ms_first = ws_ready ? c->h_mail[4] : 0u, mb_first = c->h_mail[0], groups_first = c->h_mail[7];
     uint32_t m = ms_first + mb_first;
     st.unresolved_initial = m;
-    bool compacted = ws_ready;                   // k_first_groups left the working set in upos/ug/uitem[0] (or only counted it)
+    bool lists_ready = ws_ready;                 // the lists of k_first_groups still describe the tied set
     bool keep_ready = false;                     // B.keep / B.dst describe the current tied set
-    trace("scan + keep + scan");
     // long-repeat defence: when much of the block is tied and one neighbour gap dominates the tied groups,
     // settle the periodic runs directly (forward.hiph, k_chain_*) before any doubling round
-    if (m >= n / 16 && !getenv("ARCHON_NO_CHAINS")) {
+    // (long duplicates without a period -- deep_ties and no period probe -- are pairs: the pair chains of the rounds settle
+    //  them with less per-group work than this shortcut spends on millions of two-row groups)
+    if (m >= n / 16 && !(deep_ties && p_hint == 0) && !route_off(kRtNoChains)) {
         uint32_t p = p_hint;
         bool dominant = p_hint != 0;        // the driver's period probe already named the period (and the groups may be unordered)
         if (!dominant) {
-            uint32_t *tab = B.upos[1];                      // 2 * kGapSlots words; the second working-set buffers are idle
+            uint32_t *tab = B.upos[1];                      // 2 * kGapSlots words; the second triple buffers are idle
             ARCHON_HIP_TRY(hipMemsetAsync(tab, 0, 2 * fwd::kGapSlots * sizeof(uint32_t), s));
             hipLaunchKernelGGL(fwd::k_gap_sample, dim3(div_up(div_up(n, fwd::kGapStride), 256)), dim3(256), 0, s, sa, B.v, n, tab);
             ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, tab, 2 * fwd::kGapSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -213,7 +224,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         }
         if (p >= 1 && p < n && dominant) {
             uint32_t *brk = B.rank, *ginfo = B.dst, *gend = B.keep, *settled = B.small + 601;
-            uint32_t *gmin = B.ug[1], *gmax = B.uitem[1];       // the second working-set buffers are idle
+            uint32_t *gmin = B.ug[1], *gmax = B.uitem[1];       // the second triple buffers are idle
             uint32_t *d_lastbrk = B.small + 606;
             ARCHON_HIP_TRY(hipMemsetAsync(d_lastbrk, 0, sizeof(uint32_t), s));
             hipLaunchKernelGGL(fwd::k_period_breaks, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, p, brk, d_lastbrk);
@@ -232,8 +243,8 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             c->launches += 8;
             if (c->h_mail[1] >= m) {
                 m = 0;                          // every tied row was settled: nothing to count or compact
-            } else if (c->h_mail[1] != 0 || !compacted) {
-                compacted = false;
+            } else if (c->h_mail[1] != 0 || !lists_ready) {
+                lists_ready = false;
                 keep_ready = true;
                 // the tied set again, without the settled groups
                 hipLaunchKernelGGL(fwd::k_keep_flags, dim3(g256), dim3(256), 0, s, B.v, n, B.keep);
@@ -248,163 +259,76 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             st.chain_items = c->h_mail[1];
         }
     }
-    int cur = 0;
-    const uint32_t m0 = m;
+    int cur = 0;                                 // buffer that holds the B list
     uint64_t *kT = B.keyA, *kS = B.keyB;
     uint32_t *vT = B.valA, *vS = B.valB;
     uint32_t h = h0;
-    if (m) {
-        if (!compacted) {
-            if (!keep_ready) {                   // the working set was only counted and the run shortcut did not run after all
-                hipLaunchKernelGGL(fwd::k_keep_flags, dim3(g256), dim3(256), 0, s, B.v, n, B.keep);
-                ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, n, B.scan_tmp, d_total));
-                c->launches += 3;
-            }
-            hipLaunchKernelGGL(fwd::k_compact_first, dim3(g256), dim3(256), 0, s, B.keep, B.dst, B.v, sa, n, B.upos[0], B.ug[0],
-                               B.uitem[0]);
-            ++c->launches;
-        }
-        // (round-2 route: the rows are gathered again at the end, k_bwt_fix; the two-list route writes a row's symbol
-        //  when the row becomes final)
-        if (!fused_ok) ARCHON_HIP_TRY(hipMemcpyAsync(B.uinit, B.upos[0], (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-    }
-    // Text rounds: while few items are tied, key them on the next four bytes of the text instead of on ranks -- no
-    // inverse suffix array yet (its 4N-byte scatter costs more than a whole round on a small working set).  They stop
-    // as soon as a round fails to halve the working set (long repeats: doubling is what resolves those).
-    // One round's ordering: every group of the working set sorted on its items' 32-bit keys (mode 0: rank[s-h], mode 1:
-    // the next four text bytes); on return vR[j] = the items in their new order and B.vw[j] = the row where the new
-    // group of entry j starts.  Short groups are sorted inside k_seg_round; entries of long ones go through the global
-    // radix sort -- alone if they are the minority, otherwise the whole working set does (the original route).
-    const bool seg_ok = !getenv("ARCHON_NO_SEG_ROUNDS");
-    uint32_t *d_nbig = B.small + 604;
-    auto round_sort = [&](int mode, uint32_t mm, uint32_t hh, int cu, uint32_t **vR_out) -> int {
-        const uint32_t gm = div_up(mm, 256);
-        if (seg_ok) {
-            ARCHON_HIP_TRY(hipMemsetAsync(d_nbig, 0, sizeof(uint32_t), s));
-            const uint32_t gs = div_up(mm, fwd::kSegTile);
-            if (mode == 0)
-                hipLaunchKernelGGL(fwd::k_round_keys<0>, dim3(gm), dim3(256), 0, s, B.uitem[cu], B.rank, d_x, hh, mm, B.dst);
-            else
-                hipLaunchKernelGGL(fwd::k_round_keys<1>, dim3(gm), dim3(256), 0, s, B.uitem[cu], B.rank, d_x, hh, mm, B.dst);
-            hipLaunchKernelGGL(fwd::k_seg_round, dim3(gs), dim3(256), 0, s, B.ug[cu], B.uitem[cu], B.dst, mm, kT, vT, B.vw, B.keep, d_nbig);
-            ARCHON_HIP_TRY(hipGetLastError());
-            ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_nbig, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            ARCHON_HIP_TRY(hipStreamSynchronize(s));
-            ++c->launches;
-            const uint32_t nbig = c->h_mail[0];
-            st.seg_big_items += nbig;
-            *vR_out = vT;
-            ++c->launches;
-            if (nbig == 0) return ARCHON_OK;
-            // the entries of long groups: compacted, sorted globally on (group, key), put back.  Buffers: the (group, key)
-            // pairs of k_seg_round are dead once gathered, so kT is the sort's second key buffer; the next working set's
-            // item array is idle until this round is compacted and lends the second value buffer.
-            ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, mm, B.scan_tmp, d_total));
-            hipLaunchKernelGGL(fwd::k_big_gather, dim3(gm), dim3(256), 0, s, B.keep, B.dst, kT, vT, mm, kS, vS);
-            bool b2 = false;
-            uint32_t passes = 0;
-            ARCHON_TRY(rs::sort_pairs(s, B.sc, kS, vS, kT, B.uitem[cu ^ 1], nbig, 0xFFu, &b2, &passes, &c->launches));
-            hipLaunchKernelGGL(fwd::k_big_scatter, dim3(gm), dim3(256), 0, s, B.keep, B.dst, b2 ? kT : kS, b2 ? B.uitem[cu ^ 1] : vS,
-                               B.upos[cu], mm, vT, B.vw);
-            ARCHON_TRY(launch_scan<1>(s, B.vw, B.vw, mm, B.scan_tmp, nullptr));
-            c->launches += 6;
-            return ARCHON_OK;
-        }
-        if (mode == 0)
-            hipLaunchKernelGGL(fwd::k_gather_rank, dim3(gm), dim3(256), 0, s, B.ug[cu], B.uitem[cu], B.rank, hh, mm, kT, vT);
-        else
-            hipLaunchKernelGGL(fwd::k_gather_text, dim3(gm), dim3(256), 0, s, B.ug[cu], B.uitem[cu], d_x, hh, mm, kT, vT);
-        ARCHON_HIP_TRY(hipGetLastError());
-        bool b2 = false;
-        uint32_t passes = 0;
-        ARCHON_TRY(rs::sort_pairs(s, B.sc, kT, vT, kS, vS, mm, 0xFFu, &b2, &passes, &c->launches));
-        hipLaunchKernelGGL(fwd::k_flag_round, dim3(gm), dim3(256), 0, s, b2 ? kS : kT, B.upos[cu], mm, B.vw);
-        ARCHON_TRY(launch_scan<1>(s, B.vw, B.vw, mm, B.scan_tmp, nullptr));
-        c->launches += 4;
-        *vR_out = b2 ? vS : vT;
-        return ARCHON_OK;
-    };
-    // the rest of a round: items and group starts back into the tables, survivors compacted into the next working set
-    auto round_finish = [&](bool text, uint32_t mm, int cu, uint32_t *vR, uint32_t *m2_out) -> int {
-        unsigned long long *fg_status = reinterpret_cast<unsigned long long *>(B.sc.d_status);
-        const uint32_t tiles = div_up(mm, fwd::kFgTile);
-        ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
-        ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
-        if (text)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_finish<true>), dim3(tiles), dim3(256), 0, s, vR, B.upos[cu], B.vw, B.ug[cu], mm, sa, B.v,
-                               B.upos[cu ^ 1], B.ug[cu ^ 1], B.uitem[cu ^ 1], d_total, fg_status, B.sc.d_ticket, B.sc.d_err);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_finish<false>), dim3(tiles), dim3(256), 0, s, vR, B.upos[cu], B.vw, B.ug[cu], mm, sa, B.rank,
-                               B.upos[cu ^ 1], B.ug[cu ^ 1], B.uitem[cu ^ 1], d_total, fg_status, B.sc.d_ticket, B.sc.d_err);
-        ARCHON_HIP_TRY(hipGetLastError());
-        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
-        ++c->launches;
-        *m2_out = c->h_mail[0];
-        return ARCHON_OK;
-    };
-    // ---- the two lists (rounds.hiph): S = entries of groups of at most fwd::kFuMax rows, one fused kernel per round;
-    //      B = the longer groups, on the round_sort / round_finish path above, handed over to S as they split
-    uint32_t ms = 0, mb = m, bgroups = m / 2u + 1u;
+    uint32_t ms = 0, mb = 0, bgroups = 1;
     int cs = 0;
-    // triples in buffer `from` (mm of them, in row order) -> short groups appended to S list `cs_out`, the rest to buffer `from ^ 1`
-    auto classify = [&](int from, uint32_t mm, int cs_out) -> int {
-        unsigned long long *fg_status = reinterpret_cast<unsigned long long *>(B.sc.d_status);
-        const uint32_t tiles = div_up(mm, fwd::kClT);
-        ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
-        ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
-        hipLaunchKernelGGL(fwd::k_classify, dim3(tiles), dim3(fwd::kFuLanes), 0, s, B.upos[from], B.ug[from], B.uitem[from], mm, B.slist[cs_out], d_fu,
-                           B.upos[from ^ 1], B.ug[from ^ 1], B.uitem[from ^ 1], d_fu + 2, fg_status, B.sc.d_ticket, B.sc.d_err);
-        ARCHON_HIP_TRY(hipGetLastError());
-        ++c->launches;
-        return ARCHON_OK;
-    };
-    if (m && fused_ok && compacted && lists_ready) {
+    unsigned long long *fg_status = reinterpret_cast<unsigned long long *>(B.sc.d_status);
+    if (m && lists_ready) {
         ms = ms_first;
         mb = mb_first;
         bgroups = groups_first;
-    } else if (m && fused_ok) {
-        // the run shortcut changed the tied set (or the set was only counted): triples of all of it in buffer 0 -> the lists
+    } else if (m) {
+        // the run shortcut changed the tied set (or the set was only counted): all of it as triples, then split into the
+        // lists (k_classify: short groups to S, the others stay in row order)
+        if (!keep_ready) {
+            hipLaunchKernelGGL(fwd::k_keep_flags, dim3(g256), dim3(256), 0, s, B.v, n, B.keep);
+            ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, n, B.scan_tmp, d_total));
+            c->launches += 3;
+        }
+        hipLaunchKernelGGL(fwd::k_compact_first, dim3(g256), dim3(256), 0, s, B.keep, B.dst, B.v, sa, n, B.upos[0], B.ug[0], B.uitem[0]);
+        const uint32_t tiles = div_up(m, fwd::kClT);
         ARCHON_HIP_TRY(hipMemsetAsync(d_fu, 0, 4 * sizeof(uint32_t), s));
-        ARCHON_TRY(classify(cur, m, cs));
+        ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
+        ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(fwd::k_classify, dim3(tiles), dim3(fwd::kFuLanes), 0, s, B.upos[0], B.ug[0], B.uitem[0], m, B.slist[cs], d_fu,
+                           B.upos[1], B.ug[1], B.uitem[1], d_fu + 2, fg_status, B.sc.d_ticket, B.sc.d_err);
+        ARCHON_HIP_TRY(hipGetLastError());
+        c->launches += 2;
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_fu, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         ms = c->h_mail[0];
         mb = c->h_mail[2];
         bgroups = mb / (fwd::kFuMax + 1u) + 2u;          // every group left in B is longer than kFuMax
-        cur ^= 1;
+        cur = 1;
         if (ms + mb != m) { set_error("classification lost entries (%u + %u of %u)", ms, mb, m); return ARCHON_E_INTERNAL; }
         trace("classify");
     }
-    // one round over both lists: mode 0 keys on rank[s-h], mode 1 on the next four text bytes.
-    // The rank table is read by every key gather of the round (S: k_round_fused, B: k_b_keys) before anything writes it
-    // (S: k_rank_apply, B: k_b_finish): the launches below are ordered accordingly.
-    // pair chains (rounds.hiph, k_pair_*): buffers that only the round-2 route uses otherwise
-    uint64_t *pk = reinterpret_cast<uint64_t *>(B.keep), *pk2 = reinterpret_cast<uint64_t *>(B.dst);       // n/2 records of 8 bytes each
-    uint32_t *pv = B.vw, *pv2 = B.vw + n / 2 + 1, *pair_v = B.uinit, *pair_code = B.uinit + n / 2 + 1;
-    bool chain_next = false;                     // list the pairs of the coming round and settle them by passage
+    // pair chains (rounds.hiph, k_pair_*): {smaller item, distance} records, their {row, flag} words, sort buffers, run heads
+    // (the list itself lives through the round; the chain pass behind the round's rank updates borrows the key / value
+    //  buffers of the B sort, which are idle by then)
+    uint64_t *pk = reinterpret_cast<uint64_t *>(B.keep), *pk2 = B.keyA;       // n/2 records of 8 bytes each
+    uint32_t *pv = B.pairw, *pv2 = B.valA, *pair_v = B.valA + (n / 2 + 8), *pair_code = B.valA + 2 * ((size_t)n / 2 + 8);
+    // (deep_ties: the streaming stage compared every tied group 64 symbols deep and they still agree -- long duplicates: no
+    //  text rounds, and the first doubling round already lists its pairs)
+    bool chain_next = deep_ties;                 // list the pairs of the coming round and settle them by passage
     uint32_t chain_cool = 0;
-    const bool chain_ok = fused_ok && n >= 4 && !getenv("ARCHON_NO_PAIR_CHAINS");
+    const bool chain_ok = n >= 4 && !route_off(kRtNoPairChains);
+    const bool writer_ok = n >= (1u << 22) && !route_off(kRtNoRankWriter);
+    // One round over both lists: mode 0 keys on rank[s-h], mode 1 on the next four text bytes.
+    // The rank table is read by every key gather of the round (S: k_round_fused, B: k_b_keys) before anything writes it
+    // (S: the log, applied at the end; B: k_b_finish): the launches below are ordered accordingly.
     auto do_round = [&](int mode, uint32_t hh) -> int {
-        const uint32_t chain = (chain_next && mode == 0 && ms) ? 1u : 0u;
+        const uint32_t chain = (chain_next && chain_ok && mode == 0 && ms) ? 1u : 0u;
         // many rank updates: dealt by item into windows of the table (rank_writer.hiph) instead of one random store each
-        const bool writer = mode == 0 && fused_ok && n >= (1u << 22) && (uint64_t)ms + mb >= (8u << 20) && !getenv("ARCHON_NO_RANK_WRITER");
+        const bool writer = mode == 0 && writer_ok && (uint64_t)ms + mb >= (8u << 20);
         const uint32_t m_before = ms + mb;
         ARCHON_HIP_TRY(hipMemsetAsync(d_fu, 0, 6 * sizeof(uint32_t), s));
         // B: keys (the gather) now, global sort on (group, key) behind the S kernel -- which so runs while the host waits for
         // the sort's digit counts
-        uint32_t *vR = nullptr;
         uint32_t shift = 32, gbits = 1;
         if (mode == 0) { shift = 1; while ((2ull * n) >> shift) ++shift; }          // bits of a key k < 2n
         while ((uint64_t)bgroups >> gbits) ++gbits;                                 // bits of a group number of the B list
-        unsigned long long *fg_status = reinterpret_cast<unsigned long long *>(B.sc.d_status);
-        if (mb && fused_ok) {
+        const uint32_t nbytes = (shift + gbits + 7) / 8;
+        const uint32_t mb_round = mb;
+        if (mb) {
             st.seg_big_items += mb;
             const uint32_t tiles = div_up(mb, fwd::kFgTile);
             ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
             ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
             ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ghist, 0, 8 * 256 * sizeof(uint32_t), s));
-            const uint32_t nbytes = (shift + gbits + 7) / 8;
             if (mode == 0)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_keys<0>), dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], B.uitem[cur], B.rank, d_x, hh, n, shift, mb, kT, vT,
                                    fg_status, B.sc.d_ticket, B.sc.d_err, B.sc.d_ghist, nbytes);
@@ -412,8 +336,6 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_keys<1>), dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], B.uitem[cur], B.rank, d_x, hh, n, shift, mb, kT, vT,
                                    fg_status, B.sc.d_ticket, B.sc.d_err, B.sc.d_ghist, nbytes);
             ++c->launches;
-        } else if (mb) {
-            ARCHON_TRY(round_sort(mode, mb, hh, cur, &vR));
         }
         if (ms) {
             const dim3 grid(div_up(ms, fwd::kFuT)), block(fwd::kFuLanes);
@@ -424,11 +346,8 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             ARCHON_HIP_TRY(hipGetLastError());
             ++c->launches;
         }
-        uint32_t mb2 = 0;
         uint2 *b_log = nullptr;
-        const uint32_t mb_round = mb;
-        if (mb && fused_ok) {
-            const uint32_t nbytes = (shift + gbits + 7) / 8;
+        if (mb) {
             uint32_t passes = 0;
             bool b_in_b = false;
             ARCHON_TRY(rs::sort_pairs(s, B.sc, kT, vT, kS, vS, mb, (1u << nbytes) - 1u, &b_in_b, &passes, &c->launches, nullptr, nullptr, nullptr, true));
@@ -447,12 +366,10 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             ARCHON_HIP_TRY(hipGetLastError());
             ++c->launches;
             cur ^= 1;                           // (short groups that straddle a tile of that sweep stay in B for another round)
-            mb2 = 1;                            // read with the round's counters below
-        } else if (mb) {
-            ARCHON_TRY(round_finish(mode == 1, mb, cur, vR, &mb2));
-            cur ^= 1;
         }
         if (writer) {                           // the round's rank updates (S: the log; B: k_b_finish's), now that every key has been read
+            B.rwb.r1 = reinterpret_cast<uint2 *>(b_log == reinterpret_cast<uint2 *>(kT) ? kS : kT);       // the key buffer that is not the B log
+            B.rwb.r2 = reinterpret_cast<uint2 *>(B.valA);
             ARCHON_HIP_TRY(hipMemsetAsync(B.rwb.cnt1, 0, (rw::kMaxCoarse + rw::fine_buckets(n)) * sizeof(uint32_t), s));
             if (ms) hipLaunchKernelGGL(HIP_KERNEL_NAME(rw::k_part<1, 0>), dim3(div_up(ms, rw::kTile)), dim3(rw::kLanes), 0, s, B.rlog, d_fu + 1, 0u, nullptr, nullptr, nullptr, B.rwb.r1, B.rwb.cnt1);
             if (b_log) hipLaunchKernelGGL(HIP_KERNEL_NAME(rw::k_part<1, 0>), dim3(div_up(mb_round, rw::kTile)), dim3(rw::kLanes), 0, s, b_log, nullptr, mb_round, nullptr, nullptr, nullptr, B.rwb.r1, B.rwb.cnt1);
@@ -465,8 +382,8 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_fu, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         ms = c->h_mail[0];
-        mb = fused_ok ? (mb2 ? c->h_mail[2] : 0u) : mb2;
-        if (fused_ok) bgroups = c->h_mail[3];
+        mb = mb_round ? c->h_mail[2] : 0u;
+        bgroups = c->h_mail[3];
         cs ^= 1;
         uint32_t np = chain ? c->h_mail[4] : 0u;
         const uint32_t pairs_seen = chain ? np : c->h_mail[5];
@@ -496,8 +413,10 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         chain_next = chain_ok && !chain_cool && (uint64_t)m_after * 4 >= (uint64_t)m_before * 3 && (uint64_t)pairs_seen * 4 >= ms && ms;
         return ARCHON_OK;
     };
-    const bool text_ok = !getenv("ARCHON_NO_TEXT_ROUNDS");
-    while (m && text_ok && (uint64_t)m * 4 <= n && st.text_rounds < 4 && h < n) {
+    // Text rounds: while few items are tied, key them on the next four bytes of the text instead of on ranks -- no
+    // inverse suffix array yet (filling it costs more than a whole round on a small set).  They stop as soon as a round
+    // fails to halve the set (long repeats: doubling is what resolves those).
+    while (m && !route_off(kRtNoTextRounds) && !deep_ties && (uint64_t)m * 4 <= n && st.text_rounds < 4 && h < n) {
         st.unresolved_total += m;
         ++st.text_rounds;
         trace("before text round");
@@ -510,10 +429,12 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         if (!productive) break;
     }
     if (m) {
-        // ranks are needed only now (4N random stores): every item, not just the tied ones
+        // ranks are needed only now: rank[sa[i]] = first row of the group of row i, for every row
         trace("before scatter_rank");
-        if (n >= (1u << 22) && !getenv("ARCHON_NO_RANK_WRITER")) {
-            // rank[sa[i]] = gstart[i] dealt by item into windows of the table (rank_writer.hiph) instead of n random stores
+        if (writer_ok) {
+            // ... dealt by item into windows of the table (rank_writer.hiph) instead of n random stores
+            B.rwb.r1 = reinterpret_cast<uint2 *>(B.keyA);           // (the first stage's pairs / records are dead)
+            B.rwb.r2 = reinterpret_cast<uint2 *>(B.valA);
             ARCHON_HIP_TRY(hipMemsetAsync(B.rwb.cnt1, 0, (rw::kMaxCoarse + rw::fine_buckets(n)) * sizeof(uint32_t), s));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(rw::k_part<1, 1>), dim3(div_up(n, rw::kTile)), dim3(rw::kLanes), 0, s, nullptr, nullptr, n, sa, B.v, nullptr, B.rwb.r1, B.rwb.cnt1);
             ARCHON_TRY(rw::write_back(s, B.rwb, n, B.rank, &c->launches));
@@ -530,14 +451,12 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         const auto t0 = std::chrono::steady_clock::now();
         const uint32_t ms0 = ms, mb0 = mb;
-        const uint64_t big0 = st.seg_big_items;
 #endif
         ARCHON_TRY(do_round(0, h));
 #ifdef ARCHON_EXPERIMENTS
         if (getenv("ARCHON_TRACE_ROUNDS")) {
             const auto t1 = std::chrono::steady_clock::now();
-            fprintf(stderr, "round h=%u S=%u B=%u (sorted globally %llu) %.3f ms -> S=%u B=%u\n", h, ms0, mb0, (unsigned long long)(st.seg_big_items - big0),
-                    std::chrono::duration<double, std::milli>(t1 - t0).count(), ms, mb);
+            fprintf(stderr, "round h=%u S=%u B=%u %.3f ms -> S=%u B=%u\n", h, ms0, mb0, std::chrono::duration<double, std::milli>(t1 - t0).count(), ms, mb);
             if (ms0 && getenv("ARCHON_TRACE_STAMPS")) {
                 unsigned long long v[24];
                 if (hipMemcpyFromSymbol(v, HIP_SYMBOL(fwd::g_fu_stamps), sizeof v) == hipSuccess) {
@@ -555,13 +474,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         }
         h = h > 0x40000000u ? 0x80000000u : h * 2;
     }
-    // A7 for the rows the doubling rounds moved (every other row already holds its symbol)
     trace("rounds done");
-    if (m0 && !fused_ok) {
-        hipLaunchKernelGGL(fwd::k_bwt_fix, dim3(div_up(m0, 256)), dim3(256), 0, s, d_x, sa, B.uinit, m0, n, d_bwt, d_base);
-        ARCHON_HIP_TRY(hipGetLastError());
-        ++c->launches;
-    }
     return ARCHON_OK;
 }
 
@@ -578,22 +491,20 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     FwdBuf B;
     B.xa = c->alloc<uint8_t>((size_t)n + 64);
     B.y = c->alloc<uint8_t>((size_t)n + 64);
-    B.keyA = c->alloc<uint64_t>((size_t)n + 8);
-    B.keyB = c->alloc<uint64_t>((size_t)n + 8);
-    B.valA = c->alloc<uint32_t>((size_t)n + 16);
-    B.valB = c->alloc<uint32_t>((size_t)n + 16);
+    B.keyA = c->alloc<uint64_t>(key_words(n));
+    B.keyB = c->alloc<uint64_t>(key_words(n));
+    B.valA = reinterpret_cast<uint32_t *>(c->alloc<uint64_t>(key_words(n)));
+    B.valB = B.valA ? B.valA + ((size_t)n + 16) : nullptr;
     B.rank = c->alloc<uint32_t>((size_t)n + 1);
     B.sa_own = c->alloc<uint32_t>(n);
     B.v = c->alloc<uint32_t>(n);
     B.keep = c->alloc<uint32_t>(n);
-    B.dst = c->alloc<uint32_t>(n);
     for (int i = 0; i < 2; ++i) {
         B.upos[i] = c->alloc<uint32_t>(n);
         B.ug[i] = c->alloc<uint32_t>(n);
         B.uitem[i] = c->alloc<uint32_t>(n);
     }
-    B.uinit = c->alloc<uint32_t>(n);
-    B.vw = c->alloc<uint32_t>(n);                  // group starts of the working set inside a round (B.v stays the full table)
+    B.pairw = c->alloc<uint32_t>((size_t)n / 2 + 8);
     B.scan_tmp = c->alloc<uint32_t>(scan_temp_words(n));
     B.sc.d_status = c->alloc<uint32_t>(rs::status_words(n));
     B.sc.d_ghist = c->alloc<uint32_t>(8 * 256);
@@ -608,10 +519,10 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     B.slist[0] = c->alloc<uint2>((size_t)n + 8);
     B.slist[1] = c->alloc<uint2>((size_t)n + 8);
     B.rlog = c->alloc<uint2>((size_t)n + 8);
-    B.rwb.r1 = c->alloc<uint2>(rw::region_records(n));
-    B.rwb.r2 = c->alloc<uint2>(rw::region_records(n));
+    B.dst = reinterpret_cast<uint32_t *>(B.rlog);               // (scratch of the run shortcut / the scans before the rounds)
+    B.rwb.r1 = B.rwb.r2 = nullptr;
     B.rwb.cnt1 = c->alloc<uint32_t>(rw::kMaxCoarse + rw::fine_buckets(n) + 64);
-    B.rwb.cnt2 = B.rwb.cnt1 + rw::kMaxCoarse;
+    B.rwb.cnt2 = B.rwb.cnt1 ? B.rwb.cnt1 + rw::kMaxCoarse : nullptr;
     if (!B.small || !B.rlog || !B.rwb.cnt1) {
         set_error("arena exhausted");
         return ARCHON_E_NOMEM;
@@ -646,10 +557,9 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // (shorter tails while RCCL's kernels hold CUs); tests use odd counts.  Whatever is asked for, a range never
     // exceeds 2^24 items (pass A stages positions relative to its range start in 24 bits).
     uint32_t R = (uint32_t)kNumCU;
-    if (const char *e = getenv("ARCHON_PASS_RANGES")) {
-        const long v = strtol(e, nullptr, 10);
-        if (v < 1 || v > bs::kMaxRanges) { set_error("ARCHON_PASS_RANGES=%s out of range [1, %d]", e, bs::kMaxRanges); return ARCHON_E_ARG; }
-        R = (uint32_t)v;
+    if (g_route.pass_ranges) {
+        if (g_route.pass_ranges > (uint32_t)bs::kMaxRanges) { set_error("pass ranges %u out of range [1, %d]", g_route.pass_ranges, bs::kMaxRanges); return ARCHON_E_ARG; }
+        R = g_route.pass_ranges;
     }
     if (R > ntiles) R = ntiles;
     uint32_t tpr = div_up(ntiles, R);
@@ -668,7 +578,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // device, the whole streaming stage is queued behind it, and its kernels return at once when the flag says
     // "skewed".  One host round trip per block (after k_resolve_ties) instead of two.
     // bucket-per-workgroup pass B (Prep::aligned) needs 256 workgroups and enough tiles per bucket to matter
-    const uint32_t allow_aligned = (n >= (1u << 24) && !getenv("ARCHON_NO_ALIGNED")) ? 1u : 0u;
+    const uint32_t allow_aligned = (n >= (1u << 24) && !route_off(kRtNoAligned)) ? 1u : 0u;
     int e1 = -1;
     auto count16 = [&](int Q, const uint8_t *src, bool force_stream, bool probe = false, bool hot = false) -> int {
         uint32_t *d_suspect = probe ? &B.prep->suspect : nullptr;
@@ -766,14 +676,13 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         return ARCHON_OK;
     };
     // entry of the general stage (k_first_groups): clean SA, group starts and the compacted working set in one sweep
-    const bool fused_ok = !getenv("ARCHON_NO_FUSED");        // (tests: the round-2 route, one ordered list of triples)
     auto first_groups = [&](int mode, const uint64_t *keys, const uint32_t *items, uint32_t shift, bool write_ws) -> int {
         unsigned long long *fg_status = reinterpret_cast<unsigned long long *>(B.sc.d_status);
         const uint32_t tiles = div_up(n, fwd::kFgTile);
         ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
         ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
         ARCHON_HIP_TRY(hipMemsetAsync(small + 700, 0, 4 * sizeof(uint32_t), s));
-        const uint32_t ws_mode = !write_ws ? 0u : fused_ok ? 2u : 1u;      // 2: the S / B lists of rounds.hiph
+        const uint32_t ws_mode = write_ws ? 2u : 0u;      // 2: the S / B lists of rounds.hiph
         if (mode == 0)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_first_groups<0>), dim3(tiles), dim3(256), 0, s, keys, items, shift, n, sa, d_bwt, d_base, B.v,
                                B.upos[0], B.ug[0], B.uitem[0], small + 600, fg_status, B.sc.d_ticket, B.sc.d_err, ws_mode, B.slist[0], small + 700, (uint32_t)fwd::kFuMax);
@@ -784,11 +693,10 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ++c->launches;
         return ARCHON_OK;
     };
-    int forced = -1;                             // ARCHON_FORCE_PATH (tests): 0 = 7-pass route, 1 = streaming stage
-    if (const char *f = getenv("ARCHON_FORCE_PATH")) forced = atoi(f) ? 1 : 0;
+    const int forced = g_route.force_path;       // (tests): 0 = 7-pass route, 1 = streaming stage, -1 = the block decides
     int path;
     int Q = 1;                                   // symbols per key byte on the streaming path
-    const bool probe = forced < 0 && !getenv("ARCHON_NO_PROBE");
+    const bool probe = forced < 0 && !route_off(kRtNoProbe);
     ARCHON_TRY(count16(1, d_x, forced == 1, probe));
     if (forced == 0) {
         ARCHON_TRY(count_wait());
@@ -812,7 +720,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             h_lut[v] = (uint8_t)sigma;
             if ((c->h_mail[520 + (v >> 5)] >> (v & 31u)) & 1u) ++sigma;
         }
-        if (sigma <= 16 && !getenv("ARCHON_NO_PACK")) {
+        if (sigma <= 16 && !route_off(kRtNoPack)) {
             have_lut = true;
             path = 0;
         } else {
@@ -827,7 +735,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // passes after all -- two key bytes, its oversized buckets handed on as groups tied at depth 2 (k_unpack_big) --
     // or, with that route switched off, three key bytes of the 7-pass sort.
     uint32_t key_bytes = fwd::kKeyBytes, period_hint = 0;
-    if (path == 0 && n >= (1u << 16) && !getenv("ARCHON_NO_PERIOD_PROBE")) {
+    if (path == 0 && n >= (1u << 16) && !route_off(kRtNoPeriodProbe)) {
         uint32_t *pres = small + 610;
         c->h_mail[0] = 0xFFFFFFFFu; c->h_mail[1] = 0;
         ARCHON_HIP_TRY(hipMemcpyAsync(pres, c->h_mail, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
@@ -842,10 +750,10 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             // two bytes at two places of the motif) is no run, and sorting it out at depth 2 costs more than a third key
             // byte.  The two-byte count tells: a single run holds n / p items.  (Periods 1 and 2 cannot collide.)
             const uint32_t pp = c->h_mail[0];
-            if (!getenv("ARCHON_NO_PERIOD_HINT")) period_hint = pp;     // the run shortcut need not sample neighbour gaps for it
+            if (!route_off(kRtNoPeriodHint)) period_hint = pp;     // the run shortcut need not sample neighbour gaps for it
             const bool count_ok = forced < 0 && !h_ctl.suspect;
             const bool single_runs = pp <= 2 || (count_ok && (uint64_t)h_ctl.max_bucket * 2 * pp <= (uint64_t)n * 3);
-            if (forced < 0 && single_runs && !getenv("ARCHON_NO_PERIOD_STREAM")) {
+            if (forced < 0 && single_runs && !route_off(kRtNoPeriodStream)) {
                 period_hint = pp;               // (the streaming passes keep no order inside a bucket: gap sampling would not work)
                 ARCHON_TRY(count16(1, d_x, true, false, true));
                 ARCHON_TRY(streaming(1, d_x, true));
@@ -869,10 +777,10 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         }
         bits = 1;
         while ((1u << bits) < sigma) ++bits;
-        if (sigma <= 16 && !getenv("ARCHON_NO_PACK")) {
+        if (sigma <= 16 && !route_off(kRtNoPack)) {
             memcpy(c->h_mail + 1024, h_lut, 256);
             ARCHON_HIP_TRY(hipMemcpyAsync(d_lut, c->h_mail + 1024, 256, hipMemcpyHostToDevice, s));
-            if (sigma >= 2 && forced < 0 && !getenv("ARCHON_NO_PACK_STREAM")) {
+            if (sigma >= 2 && forced < 0 && !route_off(kRtNoPackStream)) {
                 const int q = bits == 1 ? 8 : bits == 2 ? 4 : 2;
                 const dim3 grid(div_up(div_up(n, 16), 256)), block(256);
                 if (q == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_build_y<8>), grid, block, 0, s, d_x, n, d_lut, B.y);
@@ -917,7 +825,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     } else {
         // ---- first stage for heavily skewed blocks: LSB passes on packed 7-byte keys ----
         // alphabet compaction: with <= 16 distinct bytes the key holds 56/bits symbols
-        const bool packed = sigma <= 16 && !getenv("ARCHON_NO_PACK");
+        const bool packed = sigma <= 16 && !route_off(kRtNoPack);
         static thread_local uint32_t hist_given[8 * 256];
         bool use_given = false;
         if (packed) {
@@ -968,7 +876,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     }
 
     if (need_general) {
-        ARCHON_TRY(general_stage(c, s, B, d_x, n, sa, h0, d_bwt, d_base, st, period_hint, ws_ready, fused_ok));
+        const bool deep_ties = path == 1 && big_items == 0 && h_ctl.min_depth >= 5 && (uint64_t)h_ctl.unresolved * 64 >= n && !route_off(kRtNoDeepHint);
+        ARCHON_TRY(general_stage(c, s, B, d_x, n, sa, h0, d_bwt, d_base, st, period_hint, ws_ready, deep_ties));
         e4 = tm.mark();
         ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, d_base, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
@@ -1440,6 +1349,35 @@ int archon_hip_exp_fu_stamps(unsigned long long out[24])
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(fwd::g_fu_stamps), 24 * sizeof(unsigned long long)) == hipSuccess ? ARCHON_OK : ARCHON_E_HIP;
 }
 #endif
+
+/* include/archon_hip_test.h: test-only routing (every route yields the same a7 order; see common.hiph, struct Route) */
+int archon_hip_test_route(const char *name, long value)
+{
+    if (!name) { set_error("null pointer"); return ARCHON_E_ARG; }
+    static const struct { const char *name; uint32_t bit; } kFlags[] = {
+        {"NO_ALIGNED", kRtNoAligned}, {"NO_CHAINS", kRtNoChains}, {"NO_DEEP_HINT", kRtNoDeepHint}, {"NO_PACK", kRtNoPack},
+        {"NO_PACK_STREAM", kRtNoPackStream}, {"NO_PAIR_CHAINS", kRtNoPairChains}, {"NO_PERIOD_HINT", kRtNoPeriodHint},
+        {"NO_PERIOD_PROBE", kRtNoPeriodProbe}, {"NO_PERIOD_STREAM", kRtNoPeriodStream}, {"NO_PROBE", kRtNoProbe},
+        {"NO_RANK_WRITER", kRtNoRankWriter}, {"NO_TEXT_ROUNDS", kRtNoTextRounds},
+    };
+    if (!strcmp(name, "RESET")) { g_route = Route(); return ARCHON_OK; }
+    if (!strcmp(name, "FORCE_PATH")) { g_route.force_path = value < 0 ? -1 : (value ? 1 : 0); return ARCHON_OK; }
+    if (!strcmp(name, "PASS_RANGES")) {
+        if (value < 0 || value > bs::kMaxRanges) { set_error("PASS_RANGES=%ld out of range [1, %d]", value, bs::kMaxRanges); return ARCHON_E_ARG; }
+        g_route.pass_ranges = (uint32_t)value;
+        return ARCHON_OK;
+    }
+    if (!strcmp(name, "INV_SLAB")) { g_route.inv_slab = value > 0 ? (uint32_t)value : 0u; return ARCHON_OK; }
+    if (!strcmp(name, "INV_SBITS")) { g_route.inv_sbits = (int)value; return ARCHON_OK; }
+    if (!strcmp(name, "INV_WALK_WGS")) { g_route.inv_walk_wgs = (int)value; return ARCHON_OK; }
+    for (const auto &f : kFlags)
+        if (!strcmp(name, f.name)) {
+            if (value) g_route.flags |= f.bit; else g_route.flags &= ~f.bit;
+            return ARCHON_OK;
+        }
+    set_error("unknown route '%s'", name);
+    return ARCHON_E_ARG;
+}
 
 int archon_hip_get_stats(int dev, archon_hip_stats *out)
 {

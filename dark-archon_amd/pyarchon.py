@@ -85,16 +85,44 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = i32
+    lib.archon_hip_test_route.argtypes = [ctypes.c_char_p, ctypes.c_long]      # include/archon_hip_test.h (tests only)
+    lib.archon_hip_test_route.restype = i32
     return lib
 
 
 _lib = None
+_routes_seen = None
+# Test routing (include/archon_hip_test.h): the library reads nothing from the environment; the tests, bench.py and the
+# tools keep saying ARCHON_<NAME>=<value> in os.environ, and this binding hands what it finds to archon_hip_test_route
+# before the next call into the library.
+_ROUTE_NAMES = ("FORCE_PATH", "PASS_RANGES", "INV_SLAB", "INV_SBITS", "INV_WALK_WGS", "NO_ALIGNED", "NO_CHAINS", "NO_DEEP_HINT",
+                "NO_PACK", "NO_PACK_STREAM", "NO_PAIR_CHAINS", "NO_PERIOD_HINT", "NO_PERIOD_PROBE", "NO_PERIOD_STREAM", "NO_PROBE",
+                "NO_RANK_WRITER", "NO_TEXT_ROUNDS")
+
+
+def _sync_routes(L):
+    global _routes_seen
+    now = tuple(os.environ.get("ARCHON_" + k) for k in _ROUTE_NAMES)
+    if now == _routes_seen:
+        return
+    _routes_seen = now
+    L.archon_hip_test_route(b"RESET", 0)
+    for k, v in zip(_ROUTE_NAMES, now):
+        if v is None:
+            continue
+        try:
+            iv = int(v)
+        except ValueError:
+            iv = 1
+        if L.archon_hip_test_route(k.encode(), iv) < 0:
+            raise ArchonError(-1, L.archon_hip_last_error().decode("utf-8", "replace"))
 
 
 def lib():
     global _lib
     if _lib is None:
         _lib = load()
+    _sync_routes(_lib)
     return _lib
 
 

@@ -25,6 +25,24 @@ def test_hip_library_exports_header():
     for name in names:
         assert hasattr(lib, name), name
     assert set(pyarchon.SYMBOLS) <= set(names)
+    for name in declared_functions("archon_hip_test.h"):          # the test-only routing entry point
+        assert hasattr(lib, name), name
+
+
+def test_library_reads_no_routing_from_the_environment():
+    """routes are chosen through archon_hip_test_route (include/archon_hip_test.h), never through the
+    environment of whoever links the library -- no getenv of a route name is compiled into the product sources."""
+    import glob
+    import pyarchon
+    src = ""
+    for path in glob.glob(os.path.join(ROOT, "dark-archon_amd", "csrc", "*")):
+        text = open(path).read()
+        text = re.sub(r"#ifdef ARCHON_EXPERIMENTS.*?#endif", "", text, flags=re.S)     # the experiments library (tools/) may
+        src += text
+    assert "getenv" not in src
+    lib = pyarchon.lib()
+    assert lib.archon_hip_test_route(b"NO_CHAINS", 1) == 0 and lib.archon_hip_test_route(b"RESET", 0) == 0
+    assert lib.archon_hip_test_route(b"NO_SUCH_ROUTE", 1) < 0 and lib.archon_hip_test_route(b"PASS_RANGES", 5000) < 0
 
 
 def test_host_library_exports_header():

@@ -277,12 +277,11 @@ def _seg_cases():
 @pytest.mark.parametrize("name", sorted(_seg_cases()))
 def test_segmented_rounds(archon, oracle, name, monkeypatch):
     """Refinement rounds (text rounds and prefix doubling) with short groups sorted in LDS (k_round_fused over the S list)
-    and long groups through the global sort (B list), in every mix: same order as the oracle, and the same on the round-2
-    route (one ordered list, k_seg_round) with and without its segmented sort."""
+    and long groups through the global sort (B list), in every mix, with and without the shortcuts: same order as the oracle."""
     x = _seg_cases()[name]
     P, B, b0 = oracle.forward(x)
-    for env in ({}, {"ARCHON_FORCE_PATH": "0"}, {"ARCHON_NO_TEXT_ROUNDS": "1", "ARCHON_NO_CHAINS": "1"}, {"ARCHON_NO_FUSED": "1"},
-                {"ARCHON_NO_FUSED": "1", "ARCHON_NO_SEG_ROUNDS": "1"}):
+    for env in ({}, {"ARCHON_FORCE_PATH": "0"}, {"ARCHON_NO_TEXT_ROUNDS": "1", "ARCHON_NO_CHAINS": "1"}, {"ARCHON_NO_PAIR_CHAINS": "1"},
+                {"ARCHON_FORCE_PATH": "0", "ARCHON_NO_TEXT_ROUNDS": "1", "ARCHON_NO_PAIR_CHAINS": "1", "ARCHON_NO_CHAINS": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         sa, bwt, base = archon.forward(x)
