@@ -325,7 +325,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         const uint32_t mb_round = mb;
         if (mb) {
             st.seg_big_items += mb;
-            const uint32_t tiles = div_up(mb, fwd::kFgTile);
+            const uint32_t tiles = div_up(mb, fwd::kBfTile);
             ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
             ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
             ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ghist, 0, 8 * 256 * sizeof(uint32_t), s));
@@ -351,7 +351,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             uint32_t passes = 0;
             bool b_in_b = false;
             ARCHON_TRY(rs::sort_pairs(s, B.sc, kT, vT, kS, vS, mb, (1u << nbytes) - 1u, &b_in_b, &passes, &c->launches, nullptr, nullptr, nullptr, true));
-            const uint32_t tiles = div_up(mb, fwd::kFgTile);
+            const uint32_t tiles = div_up(mb, fwd::kBfTile);
             ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
             ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
             const uint64_t *ks = b_in_b ? kS : kT;
