@@ -119,7 +119,13 @@ int ctx_io(Ctx *c, int slot, size_t bytes, void **out)
 //        between rounds, when all of that is dead -- the rank writer's two record regions and the pair chains' sort buffers
 //   rlog (8N)   the S rounds' rank log; before the rounds: scratch of the run shortcut / the scans (B.dst)
 //   keep (4N)   scratch of the run shortcut and the recount; in the rounds: the pair list
-static size_t key_words(uint32_t n) { const size_t r = rw::region_records(n); return r > (size_t)n + 8 ? r : (size_t)n + 8; }      // u64 words of a key buffer
+static size_t key_words(uint32_t n)          // u64 words of a key buffer (+ 512: k_local_sort's last round reads, and ignores, rows past the block)
+{
+    const size_t r = rw::region_records(n);
+    return (r > (size_t)n ? r : (size_t)n) + 520;
+}
+// partial tables of the two-byte count: one per workgroup, at most 256 of them unless a test asks for more pass ranges
+static uint32_t h16_parts() { return g_route.pass_ranges > 256u ? (uint32_t)bs::kMaxRanges : 256u; }
 static size_t forward_arena_bytes(uint32_t n)
 {
     const size_t N = n;
@@ -142,7 +148,7 @@ static size_t forward_arena_bytes(uint32_t n)
     add(sizeof(bs::Prep));
     add(sizeof(uint2) * kTieListCap);
     add(sizeof(uint4) * (size_t)bs::kMaxRanges * bs::kTrashWords);
-    add(4 * (size_t)bs::kMaxRanges * 32768u);     // partial two-byte counts
+    add(4 * (size_t)h16_parts() * 32768u);        // partial two-byte counts, one table per workgroup of the count
     add(4 * 1024);                            // counts, starts, ticket, err, base, totals, TieCtl
     add(8 * N + 64); add(8 * N + 64); add(8 * N + 64);      // the S lists of the refinement rounds (double-buffered) and the rank log
     add(4 * (rw::kMaxCoarse + rw::fine_buckets(n) + 64));
@@ -514,7 +520,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     B.prep = c->alloc<bs::Prep>(1);                             // }  open Prep)
     B.tie_list = c->alloc<uint2>(kTieListCap);
     B.trash = c->alloc<uint4>((size_t)bs::kMaxRanges * bs::kTrashWords);
-    B.h16part = c->alloc<uint32_t>((size_t)bs::kMaxRanges * 32768u);
+    B.h16part = c->alloc<uint32_t>((size_t)h16_parts() * 32768u);
     B.small = c->alloc<uint32_t>(1024);
     B.slist[0] = c->alloc<uint2>((size_t)n + 8);
     B.slist[1] = c->alloc<uint2>((size_t)n + 8);
@@ -596,7 +602,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.h16part, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
         hipLaunchKernelGGL(bs::k_hist16_sum, dim3(32, 8), dim3(256), 0, s, B.hist16, B.h16part, nparts);
         hipLaunchKernelGGL(bs::k_rows_total, dim3(256), dim3(256), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
-        hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep, force_stream ? 1u : 0u, allow_aligned, d_ctl, (uint32_t)kTieListCap);
+        hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep, force_stream ? 1u : 0u, allow_aligned, d_ctl, (uint32_t)kTieListCap, n);
         hipLaunchKernelGGL(bs::k_col_prefix, dim3(256), dim3(1024), 0, s, rhist, R, &B.prep->skip);
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 5;

@@ -194,8 +194,7 @@ long post_unpack(const byte *in, size_t in_bytes, byte *bwt, size_t cap)
 int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev, int post)
 {
     if (ndev < 1) return -4;
-    fwrite(post ? &kSigPost : &kSig, 2, 1, fo);
-    fwrite(&bsize, 4, 1, fo);
+    if (fwrite(post ? &kSigPost : &kSig, 2, 1, fo) != 1 || fwrite(&bsize, 4, 1, fo) != 1) return -3;     // (a full disk shows here first)
     Pipe p;
     if (!p.alloc(3 * ndev, (size_t)bsize + 4)) return ARCHON_E_NOMEM;
 
