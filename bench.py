@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--shape", default="random", help="random|dna|text|a|ab|motif (graded config: random)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sa", action="store_true", help="emit BWT only (the metric is quoted WITH the SA)")
+    ap.add_argument("--gather-root", default="rotate", help="rotate (step k gathers on rank k mod N: no GPU takes in N-1 payloads "
+                    "every step) | 0 (always rank 0)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the measured configuration) | gloo (rehearsal of the N>1 "
                     "control flow on fewer GPUs than ranks: ranks share devices, the gather is staged through host memory)")
     args = ap.parse_args()
@@ -183,7 +185,7 @@ def main():
     sa_t = None if args.no_sa else torch.empty(n, dtype=torch.int32, device=dev)
     # BWT || baseId (LE), double-buffered: the gather of step k runs on RCCL's stream while step k+1 sorts
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
-    pipe = archon_shard.GatherPipe(dist, rank, world, n + 4, dev, via_host=(args.backend != "nccl"))
+    pipe = archon_shard.GatherPipe(dist, rank, world, n + 4, dev, via_host=(args.backend != "nccl"), rotate=(args.gather_root == "rotate"))
     pyarchon.reserve(n, local_rank)
 
     pass_ms, pass_cnt, stage = [], [], []
@@ -237,7 +239,8 @@ def main():
     # the exchange step: rank 0 decodes the block it received from the LAST rank (inverse BWT on its own GPU)
     # and compares with that rank's input, regenerated from the seed -- after the timed region
     gathered_ok = None
-    if dist is not None and rank == 0:
+    last_root = pipe.last_root()
+    if dist is not None and rank == last_root:
         got = gathered_last[world - 1].to(dev)
         base_r = int(got[n:].view(torch.int32).item())
         back = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -311,7 +314,7 @@ def main():
                 "backend": (dist.get_backend() if dist is not None else None),
                 "dist_world_size": (dist.get_world_size() if dist is not None else 1),
                 "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if dist is not None and args.backend == "nccl" else None),
-                "exchange": ("torch.distributed.gather (RCCL grouped send/recv) of %d bytes per rank per step, dst 0" % (n + 4)) if dist is not None else None,
+                "exchange": ("torch.distributed.gather (RCCL grouped send/recv) of %d bytes per rank per step, root %s" % (n + 4, "k mod N at step k" if args.gather_root == "rotate" else "0")) if dist is not None else None,
             },
             "roofline": {
                 "bound": "hbm",

@@ -47,15 +47,22 @@ class GatherPipe:
     gather of step k (RCCL's own stream) overlaps the sort of step k+1.  `via_host` stages through host memory
     (gloo rehearsal on fewer GPUs than ranks)."""
 
-    def __init__(self, dist, rank, world, payload_bytes, device, via_host=False, dst=0):
-        self.dist, self.rank, self.world, self.dst, self.via_host = dist, rank, world, dst, via_host
+    def __init__(self, dist, rank, world, payload_bytes, device, via_host=False, dst=0, rotate=False):
+        """rotate: the gather of step k lands on rank (dst + k) mod world instead of always on `dst` -- every rank takes its
+        turn as the root, so no GPU has to take in world - 1 payloads per step (7 x 256 MiB next to its own sort): the
+        outputs of step k (blocks k * world .. k * world + world - 1, one contiguous stretch of the container) then sit
+        on rank k mod world, which writes that stretch."""
+        self.dist, self.rank, self.world, self.dst, self.via_host, self.rotate = dist, rank, world, dst, via_host, rotate
         self.outs = [torch.empty(payload_bytes, dtype=torch.uint8, device=device) for _ in range(2)]
         gdev = torch.device("cpu") if via_host else device
         self.lists = [None, None]
-        if dist is not None and rank == dst:
+        if dist is not None and (rotate or rank == dst):
             self.lists = [[torch.empty(payload_bytes, dtype=torch.uint8, device=gdev) for _ in range(world)] for _ in range(2)]
         self.pending = [None, None]
         self.step_no = 0
+
+    def root_of(self, step):
+        return (self.dst + step) % self.world if self.rotate else self.dst
 
     def next_buffer(self):
         """payload buffer of the coming step (waits until its previous gather has completed)"""
@@ -70,7 +77,8 @@ class GatherPipe:
         self.step_no += 1
         if self.dist is not None:
             src = self.outs[k].cpu() if self.via_host else self.outs[k]
-            self.pending[k] = self.dist.gather(src, self.lists[k], dst=self.dst, async_op=True)
+            root = self.root_of(self.step_no - 1)
+            self.pending[k] = self.dist.gather(src, self.lists[k] if self.rank == root else None, dst=root, async_op=True)
 
     def drain(self):
         for k in range(2):
@@ -79,9 +87,12 @@ class GatherPipe:
                 self.pending[k] = None
 
     def last(self):
-        """(own payload buffer, gathered list on dst) of the most recent step"""
+        """(own payload buffer, gathered list -- valid on last_root() only) of the most recent step"""
         k = (self.step_no - 1) & 1
         return self.outs[k], self.lists[k]
+
+    def last_root(self):
+        return self.root_of(self.step_no - 1)
 
 
 def run_sharded(dist, rank, world, blocks, forward_fn, device="cpu"):

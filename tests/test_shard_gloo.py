@@ -68,3 +68,44 @@ def test_block_assignment():
     assert p.tolist() == [1, 2, 3, 4, 3, 2, 1]
     bwt, base = archon_shard.unpack_payload(p)
     assert bwt.tolist() == [1, 2, 3] and base == 0x01020304
+
+
+def _pipe_worker(rank, world, port, rotate, q):
+    sys.path.insert(0, os.path.join(ROOT, "dark-archon_amd"))
+    import archon_shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nbytes, steps = 1000, 5
+    pipe = archon_shard.GatherPipe(dist, rank, world, nbytes, torch.device("cpu"), via_host=True, rotate=rotate)
+    ok = True
+    for k in range(steps):
+        buf = pipe.next_buffer()
+        buf[:] = (17 * k + 3 * rank) % 251               # the payload of (step k, rank)
+        pipe.submit()
+        pipe.drain()                                      # (the bench overlaps; here every step is checked at once)
+        root = pipe.root_of(k)
+        ok = ok and root == ((k % world) if rotate else 0) and pipe.last_root() == root
+        own, got = pipe.last()
+        if rank == root:
+            for r in range(world):
+                ok = ok and bool((got[r] == (17 * k + 3 * r) % 251).all())
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rotate", [False, True])
+def test_gather_pipe_roots(rotate):
+    """bench.py's exchange step: one gather per step, on rank 0 or -- rotate -- on rank k mod N at step k"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + (os.getpid() % 1000) + (7 if rotate else 0)
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, rotate, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(2))
+    assert res == {0: True, 1: True}

@@ -27,6 +27,14 @@ cat $out/stage_times.txt
 timeout -k 10 600 python3 tools/config5.py 256 2>/dev/null | tail -1 > $out/config5.json && cat $out/config5.json
 timeout -k 10 300 python3 tools/real_text.py 256 2>/dev/null | tail -1 > $out/real_text.json && cat $out/real_text.json
 timeout -k 10 120 python3 tools/radix_dir_bench.py 2>/dev/null | tail -1 > $out/radix_dir_bench.json && cat $out/radix_dir_bench.json
+# the general stage: per-kernel device time on source text found on the box and on the prose shape; long duplicates; defects
+bash tools/prof_kernels.sh real > /dev/null 2>&1 && cp gpurun_out/prof_real.txt $out/kernels_real_text.txt
+bash tools/prof_kernels.sh prose > /dev/null 2>&1 && cp gpurun_out/prof_prose.txt $out/kernels_prose.txt
+bash tools/prof_kernels.sh text > /dev/null 2>&1 && cp gpurun_out/prof_text.txt $out/kernels_text.txt
+timeout -k 10 200 python3 tools/dup_region.py 256 32 2>/dev/null | tail -1 > $out/dup_region_256_32.json
+timeout -k 10 300 python3 tools/defect_motif.py 80 3 2>/dev/null | tail -1 > $out/defect_motif_80_3.json
+hipcc -O3 --offload-arch=gfx950 -o /tmp/gather_chain tools/micro/gather_chain.hip 2>/dev/null && timeout -k 10 300 /tmp/gather_chain > $out/micro_gather_chain.txt 2>&1
+timeout -k 10 200 python3 tools/inv_exp.py 2>/dev/null | tail -4 > $out/inverse_walk_parts.txt
 # the micro-benchmarks DESIGN.md quotes (LDS operation rates, the pass skeleton with aligned / unaligned runs)
 for m in lds_rates pass_model scatter_pass; do
   hipcc -O3 --offload-arch=gfx950 -o /tmp/$m tools/micro/$m.hip 2>/dev/null && timeout -k 10 120 /tmp/$m > $out/micro_$m.txt 2>&1
