@@ -10,6 +10,7 @@
 #include "inverse.hiph"
 
 #include <stdarg.h>
+#include <atomic>
 #include <chrono>
 #include <stdlib.h>
 #include <vector>
@@ -30,10 +31,23 @@ void set_error(const char *fmt, ...)
 Route g_route;
 
 // ------------------------------------------------------------------ contexts
-static constexpr int kMaxDev = 64;
+// Two contexts per device (arena, staging buffers, stream, mailbox each): a host thread is bound to one of them at its
+// first call (round robin) and stays there, so one thread sees exactly the single-context behaviour (archon_hip_read_bwt
+// finds the BWT its own archon_hip_forward_keep left, archon_hip_get_stats its own last call), while two threads feeding
+// one GPU -- the container's workers (host/archon_container.cpp) -- overlap: block k's device-to-host copy runs beside
+// block k+1's host-to-device copy and kernels instead of the three standing in series behind one mutex.
+static constexpr int kMaxDev = 64, kCtxPerDev = 2;
 static constexpr uint32_t kTieListCap = 1u << 20;
-static Ctx *g_ctx[kMaxDev];
+static Ctx *g_ctx[kMaxDev][kCtxPerDev];
 static std::mutex g_ctx_mu;
+static std::atomic<unsigned> g_next_slot{0};
+
+static int thread_slot()
+{
+    static thread_local int t_slot = -1;
+    if (t_slot < 0) t_slot = (int)(g_next_slot.fetch_add(1u) % (unsigned)kCtxPerDev);
+    return t_slot;
+}
 
 static int device_count()
 {
@@ -56,18 +70,19 @@ int ctx_get(int dev, Ctx **out)
         set_error("device %d out of range (have %d)", dev, ndev);
         return ARCHON_E_NODEVICE;
     }
+    const int slot = thread_slot();
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     ARCHON_HIP_TRY(hipSetDevice(dev));
-    if (!g_ctx[dev]) {
+    if (!g_ctx[dev][slot]) {
         Ctx *c = new Ctx();
         c->dev = dev;
         memset(&c->stats, 0, sizeof c->stats);
         ARCHON_HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         ARCHON_HIP_TRY(hipHostMalloc((void **)&c->h_mail, Ctx::kMailWords * sizeof(uint32_t), hipHostMallocDefault));
         ARCHON_HIP_TRY(hipMalloc((void **)&c->d_mail, Ctx::kMailWords * sizeof(uint32_t)));
-        g_ctx[dev] = c;
+        g_ctx[dev][slot] = c;
     }
-    *out = g_ctx[dev];
+    *out = g_ctx[dev][slot];
     return ARCHON_OK;
 }
 
@@ -136,6 +151,7 @@ static size_t forward_arena_bytes(uint32_t n)
     add(8 * key_words(n)); add(8 * key_words(n));       // keyA keyB
     add(8 * key_words(n));          // valA | valB
     add(4 * (N + 1));               // rank
+    add(4 * N);                     // brk: the run shortcut's break table, kept for the break-distance round
     add(4 * N);                     // sa (when the caller wants none)
     add(4 * N); add(4 * N);         // v / gstart, keep
     for (int i = 0; i < 6; ++i) add(4 * N);   // upos, ug, uitem (double-buffered): the B list
@@ -158,7 +174,7 @@ static size_t forward_arena_bytes(uint32_t n)
 struct FwdBuf {
     uint8_t *xa;
     uint64_t *keyA, *keyB;
-    uint32_t *valA, *valB, *rank, *sa_own, *v, *keep, *dst;
+    uint32_t *valA, *valB, *rank, *brk, *sa_own, *v, *keep, *dst;
     uint32_t *upos[2], *ug[2], *uitem[2], *rhist, *pairw;
     uint8_t *y;
     rw::Buffers rwb;           // rank_writer.hiph (r1 / r2 are set per use: they live in the key / value buffers)
@@ -203,6 +219,9 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     const uint32_t ms_first = ws_ready ? c->h_mail[4] : 0u, mb_first = c->h_mail[0], groups_first = c->h_mail[7];
     uint32_t m = ms_first + mb_first;
     st.unresolved_initial = m;
+    uint32_t z_period = 0;                       // period of the break table in B.brk while its rounds (do_round modes 2, 3) can still settle something
+    uint32_t z_fail = 0;                         // continuation rounds in a row that settled nothing
+    bool z_first = true;
     bool lists_ready = ws_ready;                 // the lists of k_first_groups still describe the tied set
     bool keep_ready = false;                     // B.keep / B.dst describe the current tied set
     // long-repeat defence: when much of the block is tied and one neighbour gap dominates the tied groups,
@@ -229,7 +248,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             dominant = (uint64_t)c->h_mail[best] * 4 >= total;
         }
         if (p >= 1 && p < n && dominant) {
-            uint32_t *brk = B.rank, *ginfo = B.dst, *gend = B.keep, *settled = B.small + 601;
+            uint32_t *brk = B.brk, *ginfo = B.dst, *gend = B.keep, *settled = B.small + 601;
             uint32_t *gmin = B.ug[1], *gmax = B.uitem[1];       // the second triple buffers are idle
             uint32_t *d_lastbrk = B.small + 606;
             ARCHON_HIP_TRY(hipMemsetAsync(d_lastbrk, 0, sizeof(uint32_t), s));
@@ -263,6 +282,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             trace("keep + scan again");
             st.period = p;
             st.chain_items = c->h_mail[1];
+            if (m) z_period = p;                // what is left straddles defects of the period: one break-distance round once h >= p
         }
     }
     int cur = 0;                                 // buffer that holds the B list
@@ -313,19 +333,21 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     uint32_t chain_cool = 0;
     const bool chain_ok = n >= 4 && !route_off(kRtNoPairChains);
     const bool writer_ok = n >= (1u << 22) && !route_off(kRtNoRankWriter);
-    // One round over both lists: mode 0 keys on rank[s-h], mode 1 on the next four text bytes.
+    // One round over both lists: mode 0 keys on rank[s-h], mode 1 on the next four text bytes, modes 2 and 3 (hh = the period)
+    // on the distance to the last period defect and on the rank of the item the key continues as behind it (rounds.hiph,
+    // break_key / cont_key; rank table kept as in mode 0).
     // The rank table is read by every key gather of the round (S: k_round_fused, B: k_b_keys) before anything writes it
     // (S: the log, applied at the end; B: k_b_finish): the launches below are ordered accordingly.
     auto do_round = [&](int mode, uint32_t hh) -> int {
         const uint32_t chain = (chain_next && chain_ok && mode == 0 && ms) ? 1u : 0u;
         // many rank updates: dealt by item into windows of the table (rank_writer.hiph) instead of one random store each
-        const bool writer = mode == 0 && writer_ok && (uint64_t)ms + mb >= (8u << 20);
+        const bool writer = mode != 1 && writer_ok && (uint64_t)ms + mb >= (8u << 20);
         const uint32_t m_before = ms + mb;
         ARCHON_HIP_TRY(hipMemsetAsync(d_fu, 0, 6 * sizeof(uint32_t), s));
         // B: keys (the gather) now, global sort on (group, key) behind the S kernel -- which so runs while the host waits for
         // the sort's digit counts
         uint32_t shift = 32, gbits = 1;
-        if (mode == 0) { shift = 1; while ((2ull * n) >> shift) ++shift; }          // bits of a key k < 2n
+        if (mode != 1) { shift = 1; while ((2ull * n + (mode == 2 ? 2u : 0u)) >> shift) ++shift; }    // bits of a key k < 2n (mode 2: 2n + 2)
         while ((uint64_t)bgroups >> gbits) ++gbits;                                 // bits of a group number of the B list
         const uint32_t nbytes = (shift + gbits + 7) / 8;
         const uint32_t mb_round = mb;
@@ -335,20 +357,24 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
             ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
             ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ghist, 0, 8 * 256 * sizeof(uint32_t), s));
-            if (mode == 0)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_keys<0>), dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], B.uitem[cur], B.rank, d_x, hh, n, shift, mb, kT, vT,
-                                   fg_status, B.sc.d_ticket, B.sc.d_err, B.sc.d_ghist, nbytes);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_keys<1>), dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], B.uitem[cur], B.rank, d_x, hh, n, shift, mb, kT, vT,
-                                   fg_status, B.sc.d_ticket, B.sc.d_err, B.sc.d_ghist, nbytes);
+#define ARCHON_B_KEYS(M) hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_keys<M>), dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], B.uitem[cur], B.rank, d_x, hh, n, \
+                                            shift, mb, kT, vT, fg_status, B.sc.d_ticket, B.sc.d_err, B.sc.d_ghist, nbytes, B.brk)
+            if (mode == 0) ARCHON_B_KEYS(0);
+            else if (mode == 1) ARCHON_B_KEYS(1);
+            else if (mode == 2) ARCHON_B_KEYS(2);
+            else ARCHON_B_KEYS(3);
+#undef ARCHON_B_KEYS
             ++c->launches;
         }
         if (ms) {
             const dim3 grid(div_up(ms, fwd::kFuT)), block(fwd::kFuLanes);
-            if (mode == 0)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_fused<0>), grid, block, 0, s, B.slist[cs], ms, B.rank, d_x, hh, sa, B.v, B.slist[cs ^ 1], B.rlog, d_fu, B.sc.d_err, d_bwt, d_base, n, chain, pk, pv);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_fused<1>), grid, block, 0, s, B.slist[cs], ms, B.rank, d_x, hh, sa, B.v, B.slist[cs ^ 1], B.rlog, d_fu, B.sc.d_err, d_bwt, d_base, n, chain, pk, pv);
+#define ARCHON_S_ROUND(M) hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_round_fused<M>), grid, block, 0, s, B.slist[cs], ms, B.rank, d_x, hh, sa, B.v, B.slist[cs ^ 1], B.rlog, \
+                                             d_fu, B.sc.d_err, d_bwt, d_base, n, chain, pk, pv, B.brk)
+            if (mode == 0) ARCHON_S_ROUND(0);
+            else if (mode == 1) ARCHON_S_ROUND(1);
+            else if (mode == 2) ARCHON_S_ROUND(2);
+            else ARCHON_S_ROUND(3);
+#undef ARCHON_S_ROUND
             ARCHON_HIP_TRY(hipGetLastError());
             ++c->launches;
         }
@@ -363,7 +389,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             const uint64_t *ks = b_in_b ? kS : kT;
             const uint32_t *vs = b_in_b ? vS : vT;
             b_log = writer ? reinterpret_cast<uint2 *>(b_in_b ? kT : kS) : nullptr;        // the sort's other key buffer is free now
-            if (mode == 0)
+            if (mode != 1)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_finish<0>), dim3(tiles), dim3(256), 0, s, ks, vs, B.upos[cur], B.ug[cur], mb, sa, B.rank, B.slist[cs ^ 1], d_fu,
                                    B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1], fg_status, B.sc.d_ticket, B.sc.d_err, d_x, d_bwt, d_base, n, b_log);
             else
@@ -381,7 +407,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             if (b_log) hipLaunchKernelGGL(HIP_KERNEL_NAME(rw::k_part<1, 0>), dim3(div_up(mb_round, rw::kTile)), dim3(rw::kLanes), 0, s, b_log, nullptr, mb_round, nullptr, nullptr, nullptr, B.rwb.r1, B.rwb.cnt1);
             ARCHON_TRY(rw::write_back(s, B.rwb, n, B.rank, &c->launches));
             c->launches += 2;
-        } else if (mode == 0 && ms) {           // the S list's rank updates, now that every key of the round has been read
+        } else if (mode != 1 && ms) {           // the S list's rank updates, now that every key of the round has been read
             hipLaunchKernelGGL(fwd::k_rank_apply, dim3(div_up(ms, 256)), dim3(256), 0, s, B.rlog, d_fu + 1, B.rank);
             ++c->launches;
         }
@@ -451,6 +477,41 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         trace("scatter_rank");
     }
     while (m) {
+        // Groups that straddle defects of the period: once every group is tied over a whole period, one round keyed on the
+        // distance to the last defect settles them, bar the items that share that distance and the side they leave on; those
+        // follow from the rank of the item their key continues as -- a round that is repeated while it settles something
+        // (the continuation items may have been settled by the round before) and tried again behind every doubling round
+        // until it has failed twice in a row.  h stays: what these rounds leave tied is still tied over h symbols.
+        if (z_period && h >= z_period && z_fail < 2 && !route_off(kRtNoBreakRound)) {
+            for (;;) {
+                st.unresolved_total += m;
+                ++st.break_rounds;
+                const bool distance = z_first;
+#ifdef ARCHON_EXPERIMENTS
+                ARCHON_HIP_TRY(hipStreamSynchronize(s));
+                const auto t0 = std::chrono::steady_clock::now();
+                const uint32_t ms0 = ms, mb0 = mb;
+#endif
+                ARCHON_TRY(do_round(distance ? 2 : 3, z_period));
+#ifdef ARCHON_EXPERIMENTS
+                if (getenv("ARCHON_TRACE_ROUNDS")) {
+                    const auto t1 = std::chrono::steady_clock::now();
+                    fprintf(stderr, "break round (%s) p=%u (h=%u) S=%u B=%u %.3f ms -> S=%u B=%u\n", distance ? "distance" : "continuation", z_period, h, ms0, mb0,
+                            std::chrono::duration<double, std::milli>(t1 - t0).count(), ms, mb);
+                }
+#endif
+                const uint32_t settled = m - (ms + mb);
+                st.break_settled += settled;
+                m = ms + mb;
+                z_first = false;
+                if (!m) break;
+                if (!distance) {
+                    if (settled) z_fail = 0;
+                    else { ++z_fail; break; }
+                }
+            }
+            if (!m) break;
+        }
         st.unresolved_total += m;
         ++st.doubling_rounds;
 #ifdef ARCHON_EXPERIMENTS
@@ -502,6 +563,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     B.valA = reinterpret_cast<uint32_t *>(c->alloc<uint64_t>(key_words(n)));
     B.valB = B.valA ? B.valA + ((size_t)n + 16) : nullptr;
     B.rank = c->alloc<uint32_t>((size_t)n + 1);
+    B.brk = c->alloc<uint32_t>(n);
     B.sa_own = c->alloc<uint32_t>(n);
     B.v = c->alloc<uint32_t>(n);
     B.keep = c->alloc<uint32_t>(n);
@@ -882,7 +944,12 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     }
 
     if (need_general) {
-        const bool deep_ties = path == 1 && big_items == 0 && h_ctl.min_depth >= 5 && (uint64_t)h_ctl.unresolved * 64 >= n && !route_off(kRtNoDeepHint);
+        // deep ties: the streaming stage compared the tied groups 64 symbols deep and a good part of the block still agrees
+        // (when the tie list overflowed only a sample of it was compared -- bs::kTieSample groups: they stand for the rest)
+        const bool listed_all = h_ctl.tie_groups <= kTieListCap;
+        const bool deep_ties = path == 1 && big_items == 0 && h_ctl.min_depth >= 5 && !route_off(kRtNoDeepHint) &&
+                               (listed_all ? (uint64_t)h_ctl.unresolved * 64 >= n
+                                           : (uint64_t)h_ctl.unresolved * 2 >= bs::kTieSample && (uint64_t)h_ctl.tie_items * 64 >= n);
         ARCHON_TRY(general_stage(c, s, B, d_x, n, sa, h0, d_bwt, d_base, st, period_hint, ws_ready, deep_ties));
         e4 = tm.mark();
         ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, d_base, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
@@ -1315,23 +1382,26 @@ int archon_hip_reserve(uint32_t n, int dev, size_t *bytes_or_null)
 int archon_hip_release(int dev)
 {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
-    if (dev < 0 || dev >= kMaxDev || !g_ctx[dev]) return ARCHON_OK;
-    Ctx *c = g_ctx[dev];
-    {
-        std::lock_guard<std::mutex> lk2(c->mu);
-        (void)hipSetDevice(dev);
-        (void)hipDeviceSynchronize();
-        if (c->arena) (void)hipFree(c->arena);
-        for (int i = 0; i < Ctx::kIo; ++i)
-            if (c->io[i]) (void)hipFree(c->io[i]);
-        if (c->d_mail) (void)hipFree(c->d_mail);
-        if (c->h_mail) (void)hipHostFree(c->h_mail);
-        for (int i = 0; i < Ctx::kEvents; ++i)
-            if (c->ev_pool[i]) (void)hipEventDestroy(c->ev_pool[i]);
-        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (dev < 0 || dev >= kMaxDev) return ARCHON_OK;
+    for (int slot = 0; slot < kCtxPerDev; ++slot) {
+        Ctx *c = g_ctx[dev][slot];
+        if (!c) continue;
+        {
+            std::lock_guard<std::mutex> lk2(c->mu);
+            (void)hipSetDevice(dev);
+            (void)hipDeviceSynchronize();
+            if (c->arena) (void)hipFree(c->arena);
+            for (int i = 0; i < Ctx::kIo; ++i)
+                if (c->io[i]) (void)hipFree(c->io[i]);
+            if (c->d_mail) (void)hipFree(c->d_mail);
+            if (c->h_mail) (void)hipHostFree(c->h_mail);
+            for (int i = 0; i < Ctx::kEvents; ++i)
+                if (c->ev_pool[i]) (void)hipEventDestroy(c->ev_pool[i]);
+            if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+        }
+        delete c;
+        g_ctx[dev][slot] = nullptr;
     }
-    delete c;
-    g_ctx[dev] = nullptr;
     return ARCHON_OK;
 }
 
@@ -1363,7 +1433,7 @@ int archon_hip_test_route(const char *name, long value)
     static const struct { const char *name; uint32_t bit; } kFlags[] = {
         {"NO_ALIGNED", kRtNoAligned}, {"NO_CHAINS", kRtNoChains}, {"NO_DEEP_HINT", kRtNoDeepHint}, {"NO_PACK", kRtNoPack},
         {"NO_PACK_STREAM", kRtNoPackStream}, {"NO_PAIR_CHAINS", kRtNoPairChains}, {"NO_PERIOD_HINT", kRtNoPeriodHint},
-        {"NO_PERIOD_PROBE", kRtNoPeriodProbe}, {"NO_PERIOD_STREAM", kRtNoPeriodStream}, {"NO_PROBE", kRtNoProbe},
+        {"NO_BREAK_ROUND", kRtNoBreakRound}, {"NO_PERIOD_PROBE", kRtNoPeriodProbe}, {"NO_PERIOD_STREAM", kRtNoPeriodStream}, {"NO_PROBE", kRtNoProbe},
         {"NO_RANK_WRITER", kRtNoRankWriter}, {"NO_TEXT_ROUNDS", kRtNoTextRounds},
     };
     if (!strcmp(name, "RESET")) { g_route = Route(); return ARCHON_OK; }
@@ -1388,9 +1458,11 @@ int archon_hip_test_route(const char *name, long value)
 int archon_hip_get_stats(int dev, archon_hip_stats *out)
 {
     if (!out) { set_error("null pointer"); return ARCHON_E_ARG; }
+    const int slot = thread_slot();                  // the calling thread's own context: the statistics of ITS last call
     std::lock_guard<std::mutex> lk(g_ctx_mu);
-    if (dev < 0 || dev >= kMaxDev || !g_ctx[dev]) { set_error("no context on device %d", dev); return ARCHON_E_ARG; }
-    *out = g_ctx[dev]->stats;
+    if (dev < 0 || dev >= kMaxDev || !g_ctx[dev][slot]) { set_error("no context on device %d", dev); return ARCHON_E_ARG; }
+    std::lock_guard<std::mutex> lk2(g_ctx[dev][slot]->mu);
+    *out = g_ctx[dev][slot]->stats;
     return ARCHON_OK;
 }
 

@@ -8,8 +8,8 @@
 // The block payload is the a7 transform (BWT || baseId in a7 order), not x3's own sort order.
 //
 // x3 reads, transforms and writes one block after the other (archon.c:120-142).  Here the three steps are a
-// pipeline over a ring of pinned host slots: a reader thread fills slot b mod S with block b, one worker thread per
-// GPU (block b -> GPU b mod G, the sharding rule of dark-archon_amd/archon_shard.py) runs the transform
+// pipeline over a ring of pinned host slots: a reader thread fills slot b mod S with block b, two worker threads per
+// GPU (block b -> GPU b mod G, the sharding rule of dark-archon_amd/archon_shard.py) run the transform
 // (H2D + kernels + D2H through the C ABI), a writer thread emits the blocks in order -- so the fread of block k+1
 // and the fwrite of block k-1 overlap the GPU's work on block k.
 #include <stdint.h>
@@ -106,11 +106,16 @@ struct Pipe {
     }
 };
 
-// the worker of GPU `dev`: blocks dev, dev + G, dev + 2G, ...
+// Two workers per GPU: the library keeps two contexts per device and binds a host thread to one of them, so worker w
+// (blocks w, w + 2G, w + 4G, ... on GPU w mod G -- still block b on GPU b mod G) moves its block over PCIe while its
+// twin's kernels run.
+constexpr int kWorkersPerGpu = 2;
+
+// worker `first` of `step`: blocks first, first + step, ... on GPU `dev`
 template <class Work>
-void worker_loop(Pipe &p, int dev, int ndev, Work work)
+void worker_loop(Pipe &p, int first, int step, int dev, Work work)
 {
-    for (long b = dev;; b += ndev) {
+    for (long b = first;; b += step) {
         Slot *s;
         if (!p.wait(b, kFilled, &s)) return;
         const int rc = s->n ? work(*s, dev) : 0;
@@ -196,7 +201,7 @@ int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev, int po
     if (ndev < 1) return -4;
     if (fwrite(post ? &kSigPost : &kSig, 2, 1, fo) != 1 || fwrite(&bsize, 4, 1, fo) != 1) return -3;     // (a full disk shows here first)
     Pipe p;
-    if (!p.alloc(3 * ndev, (size_t)bsize + 4)) return ARCHON_E_NOMEM;
+    if (!p.alloc((kWorkersPerGpu + 2) * ndev, (size_t)bsize + 4)) return ARCHON_E_NOMEM;
 
     std::thread reader([&] {
         for (long b = 0;; ++b) {
@@ -210,9 +215,9 @@ int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev, int po
         }
     });
     std::vector<std::thread> workers;
-    for (int d = 0; d < ndev; ++d)
-        workers.emplace_back([&, d] {
-            worker_loop(p, d, ndev, [](Slot &s, int dev) {
+    for (int w = 0; w < kWorkersPerGpu * ndev; ++w)
+        workers.emplace_back([&, w] {
+            worker_loop(p, w, kWorkersPerGpu * ndev, w % ndev, [](Slot &s, int dev) {
                 return archon_hip_forward(s.in, (uint32_t)s.n, NULL, s.out, &s.base, dev);
             });
         });
@@ -247,7 +252,7 @@ int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out)
     if (fread(&bsize, 4, 1, fi) != 1 || bsize < 8 || bsize > (1u << 28)) return -3;
     if (bsize_out) *bsize_out = bsize;
     Pipe p;
-    if (!p.alloc(3 * ndev, (size_t)bsize + 4)) return ARCHON_E_NOMEM;
+    if (!p.alloc((kWorkersPerGpu + 2) * ndev, (size_t)bsize + 4)) return ARCHON_E_NOMEM;
 
     std::thread reader([&] {
         for (long b = 0;; ++b) {
@@ -275,9 +280,9 @@ int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out)
         }
     });
     std::vector<std::thread> workers;
-    for (int d = 0; d < ndev; ++d)
-        workers.emplace_back([&, d] {
-            worker_loop(p, d, ndev, [](Slot &s, int dev) {
+    for (int w = 0; w < kWorkersPerGpu * ndev; ++w)
+        workers.emplace_back([&, w] {
+            worker_loop(p, w, kWorkersPerGpu * ndev, w % ndev, [](Slot &s, int dev) {
                 return archon_hip_inverse(s.in, (uint32_t)s.n, s.base, s.out, dev);
             });
         });

@@ -43,7 +43,7 @@ class Stats(ctypes.Structure):
         ("ms_pass_text", ctypes.c_float), ("ms_pass_rec", ctypes.c_float),
         ("alphabet_bits", ctypes.c_uint32), ("period", ctypes.c_uint32),
         ("chain_items", ctypes.c_uint32), ("text_rounds", ctypes.c_uint32), ("seg_big_items", ctypes.c_uint64),
-        ("chain_pairs", ctypes.c_uint64),
+        ("chain_pairs", ctypes.c_uint64), ("break_rounds", ctypes.c_uint32), ("break_settled", ctypes.c_uint32),
     ]
 
     def asdict(self):
@@ -96,7 +96,7 @@ _routes_seen = None
 # tools keep saying ARCHON_<NAME>=<value> in os.environ, and this binding hands what it finds to archon_hip_test_route
 # before the next call into the library.
 _ROUTE_NAMES = ("FORCE_PATH", "PASS_RANGES", "INV_SLAB", "INV_SBITS", "INV_WALK_WGS", "NO_ALIGNED", "NO_CHAINS", "NO_DEEP_HINT",
-                "NO_PACK", "NO_PACK_STREAM", "NO_PAIR_CHAINS", "NO_PERIOD_HINT", "NO_PERIOD_PROBE", "NO_PERIOD_STREAM", "NO_PROBE",
+                "NO_PACK", "NO_PACK_STREAM", "NO_PAIR_CHAINS", "NO_PERIOD_HINT", "NO_BREAK_ROUND", "NO_PERIOD_PROBE", "NO_PERIOD_STREAM", "NO_PROBE",
                 "NO_RANK_WRITER", "NO_TEXT_ROUNDS")
 
 

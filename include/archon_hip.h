@@ -159,6 +159,8 @@ typedef struct archon_hip_stats {
     uint32_t text_rounds;        /* refinement rounds keyed on the next 4 text bytes (before any doubling round) */
     uint64_t seg_big_items;      /* sum over rounds of entries in groups too long for the in-workgroup sort (sent through the global sort) */
     uint64_t chain_pairs;        /* pairs of rows settled passage by passage (long duplicates) instead of by further doubling rounds */
+    uint32_t break_rounds;       /* rounds keyed on the distance to the last defect of the period (groups that straddle defects) */
+    uint32_t break_settled;      /* rows such a round settled */
 } archon_hip_stats;
 
 int archon_hip_get_stats(int dev, archon_hip_stats *out);

@@ -258,6 +258,55 @@ def test_long_repeats_lsb_route(archon, oracle, name, hint, monkeypatch):
     assert (sa == P).all() and (bwt == B).all() and base == b0
 
 
+def _defect_cases():
+    """a motif repeated with point defects: groups that straddle the defects (never ONE clean run of the period)"""
+    rng = np.random.default_rng(4099)
+    out = {}
+    for p, n, flips in ((1, 300000, 3), (2, 400001, 4), (3, 299999, 2), (7, 500000, 5), (100, 600000, 3), (1000, 1200000, 3),
+                        (4099, 2000000, 3), (257, 700000, 12)):
+        motif = rng.integers(0, 256, size=p, dtype=np.uint8)
+        x = np.tile(motif, n // p + 1)[:n].copy()
+        for q in rng.integers(0, n, size=flips):
+            x[q] ^= np.uint8(1 + rng.integers(0, 255))
+        out["p%d_%dflips" % (p, flips)] = x
+    motif = rng.integers(0, 256, size=50, dtype=np.uint8)
+    x = np.tile(motif, 8000)
+    x[100000] = 0; x[200000] = 255; x[300000] = 0          # same phase, leaving below / above / below the periodic continuation
+    out["same_phase_signs"] = x.copy()
+    x = np.tile(motif, 8000)
+    x[120025] ^= 1; x[240025] ^= 1                          # the same defect twice: items at equal distances behind them stay tied for the rounds
+    out["twin_defects"] = x.copy()
+    x = np.tile(motif, 8000)
+    x[5] ^= 7; x[399990] ^= 9; x[200000:200003] ^= 3        # defects inside the first and the last period, and three in a row
+    out["edges_and_burst"] = x.copy()
+    x = np.concatenate([np.tile(motif, 4000), np.tile(rng.integers(0, 256, size=50, dtype=np.uint8), 4000)])   # two motifs of one period
+    x[77777] ^= 1
+    out["two_motifs"] = x
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(_defect_cases()))
+def test_period_defects(archon, oracle, name, monkeypatch):
+    """N3 beyond exact periods (a4's anchors / tandem test, direct.c:90-161,198-221): groups that straddle defects of the
+    period are settled by ONE round keyed on the distance to the last defect (rounds.hiph, break_key) once every group is tied
+    over a whole period -- same a7 order as the oracle, with that round and with it switched off."""
+    x = _defect_cases()[name]
+    P, B, b0 = oracle.forward(x)
+    sa, bwt, base = archon.forward(x)
+    st = archon.stats()
+    assert (sa == P).all(), name
+    assert (bwt == B).all() and base == b0
+    if name not in ("two_motifs", "p257_12flips"):          # (those two: parity only -- the period probe need not name a period for them)
+        assert st["period"] > 0 and st["break_rounds"] >= 1 and st["break_settled"] > 0, st
+    monkeypatch.setenv("ARCHON_NO_BREAK_ROUND", "1")
+    sa2, bwt2, base2 = archon.forward(x)
+    st2 = archon.stats()
+    assert (sa2 == P).all() and (bwt2 == B).all() and base2 == b0
+    assert st2["break_rounds"] == 0
+    if st["break_rounds"]:
+        assert st["doubling_rounds"] < st2["doubling_rounds"], (st, st2)
+
+
 def _seg_cases():
     rng = np.random.default_rng(77)
     r = lambda k, hi=256: rng.integers(0, hi, size=k, dtype=np.uint8)
