@@ -181,7 +181,18 @@ def gen_prose(n, seed=SEED_BASE + 6):
     return x
 
 
-SHAPES = ("text", "random", "dna", "a", "ab", "motif", "prose")
+def gen_motif_defects(n, motif_len=4099, defects=5, seed=SEED_BASE + 7):
+    """cfg 3 with defects ("Gauntlet-style with glitches"): a `motif_len`-byte random motif repeated, `defects` single bytes
+    changed at seeded positions -- every tied group straddles the defects, none is one clean run of the period."""
+    x = gen_repeat(n, gen_random(motif_len, seed).tobytes()).copy()
+    w = splitmix64_words(seed ^ 0x5DEFEC75, 0, 2 * defects)
+    for k in range(defects):
+        q = int(w[2 * k] % np.uint64(n))
+        x[q] ^= np.uint8(1 + int(w[2 * k + 1] % np.uint64(255)))
+    return x
+
+
+SHAPES = ("text", "random", "dna", "a", "ab", "motif", "prose", "motif_defects")
 
 
 def gen_shape(shape, n, block=0):
@@ -200,4 +211,6 @@ def gen_shape(shape, n, block=0):
         return gen_motif(n, 1000, SEED_BASE + 3 + block)
     if shape == "prose":
         return gen_prose(n, SEED_BASE + 6 + block)
+    if shape == "motif_defects":
+        return gen_motif_defects(n, 4099, 5, SEED_BASE + 7 + block)
     raise ValueError(shape)

@@ -221,6 +221,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     st.unresolved_initial = m;
     uint32_t z_period = 0;                       // period of the break table in B.brk while its rounds (do_round modes 2, 3) can still settle something
     uint32_t z_fail = 0;                         // continuation rounds in a row that settled nothing
+    uint32_t z_breaks = 0;                       // positions where the text stops repeating at that distance
     bool z_first = true;
     bool lists_ready = ws_ready;                 // the lists of k_first_groups still describe the tied set
     bool keep_ready = false;                     // B.keep / B.dst describe the current tied set
@@ -251,7 +252,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             uint32_t *brk = B.brk, *ginfo = B.dst, *gend = B.keep, *settled = B.small + 601;
             uint32_t *gmin = B.ug[1], *gmax = B.uitem[1];       // the second triple buffers are idle
             uint32_t *d_lastbrk = B.small + 606;
-            ARCHON_HIP_TRY(hipMemsetAsync(d_lastbrk, 0, sizeof(uint32_t), s));
+            ARCHON_HIP_TRY(hipMemsetAsync(d_lastbrk, 0, 2 * sizeof(uint32_t), s));      // [0] last real break, [1] how many
             hipLaunchKernelGGL(fwd::k_period_breaks, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, p, brk, d_lastbrk);
             ARCHON_TRY(launch_scan<1>(s, brk, brk, n, B.scan_tmp, nullptr));
             hipLaunchKernelGGL(fwd::k_chain_init, dim3(g256), dim3(256), 0, s, B.v, n, gmin, gmax, ginfo);
@@ -264,7 +265,9 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             hipLaunchKernelGGL(fwd::k_chain_apply, dim3(div_up(n, fwd::kChainRows)), dim3(256), 0, s, sa, B.v, ginfo, gend, gmin, gmax, brk, d_lastbrk, d_x, n, p, d_bwt, d_base, settled);
             trace("chain_apply");
             ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 1, settled, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 2, d_lastbrk + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             ARCHON_HIP_TRY(hipStreamSynchronize(s));
+            z_breaks = c->h_mail[2];
             c->launches += 8;
             if (c->h_mail[1] >= m) {
                 m = 0;                          // every tied row was settled: nothing to count or compact
@@ -338,12 +341,18 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     // break_key / cont_key; rank table kept as in mode 0).
     // The rank table is read by every key gather of the round (S: k_round_fused, B: k_b_keys) before anything writes it
     // (S: the log, applied at the end; B: k_b_finish): the launches below are ordered accordingly.
-    auto do_round = [&](int mode, uint32_t hh) -> int {
+    // b_only (modes 2, 3 with certified groups, `cert` = the marks of k_zone_certify): the S list sits the round out;
+    // groups of the B list that have become short are appended to it where it is.
+    auto do_round = [&](int mode, uint32_t hh, bool b_only = false, const uint8_t *cert = nullptr, const uint32_t *okey = nullptr) -> int {
+        const uint32_t ms_kept = b_only ? ms : 0u;
+        if (b_only) ms = 0;
         const uint32_t chain = (chain_next && chain_ok && mode == 0 && ms) ? 1u : 0u;
         // many rank updates: dealt by item into windows of the table (rank_writer.hiph) instead of one random store each
         const bool writer = mode != 1 && writer_ok && (uint64_t)ms + mb >= (8u << 20);
         const uint32_t m_before = ms + mb;
         ARCHON_HIP_TRY(hipMemsetAsync(d_fu, 0, 6 * sizeof(uint32_t), s));
+        if (ms_kept) ARCHON_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_fu, (int)ms_kept, 1, s));      // k_b_finish appends behind the kept entries
+        uint2 *s_next = b_only ? B.slist[cs] : B.slist[cs ^ 1];
         // B: keys (the gather) now, global sort on (group, key) behind the S kernel -- which so runs while the host waits for
         // the sort's digit counts
         uint32_t shift = 32, gbits = 1;
@@ -358,7 +367,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
             ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ghist, 0, 8 * 256 * sizeof(uint32_t), s));
 #define ARCHON_B_KEYS(M) hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_keys<M>), dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], B.uitem[cur], B.rank, d_x, hh, n, \
-                                            shift, mb, kT, vT, fg_status, B.sc.d_ticket, B.sc.d_err, B.sc.d_ghist, nbytes, B.brk)
+                                            shift, mb, kT, vT, fg_status, B.sc.d_ticket, B.sc.d_err, B.sc.d_ghist, nbytes, B.brk, cert, okey)
             if (mode == 0) ARCHON_B_KEYS(0);
             else if (mode == 1) ARCHON_B_KEYS(1);
             else if (mode == 2) ARCHON_B_KEYS(2);
@@ -390,10 +399,10 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             const uint32_t *vs = b_in_b ? vS : vT;
             b_log = writer ? reinterpret_cast<uint2 *>(b_in_b ? kT : kS) : nullptr;        // the sort's other key buffer is free now
             if (mode != 1)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_finish<0>), dim3(tiles), dim3(256), 0, s, ks, vs, B.upos[cur], B.ug[cur], mb, sa, B.rank, B.slist[cs ^ 1], d_fu,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_finish<0>), dim3(tiles), dim3(256), 0, s, ks, vs, B.upos[cur], B.ug[cur], mb, sa, B.rank, s_next, d_fu,
                                    B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1], fg_status, B.sc.d_ticket, B.sc.d_err, d_x, d_bwt, d_base, n, b_log);
             else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_finish<1>), dim3(tiles), dim3(256), 0, s, ks, vs, B.upos[cur], B.ug[cur], mb, sa, B.v, B.slist[cs ^ 1], d_fu,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_finish<1>), dim3(tiles), dim3(256), 0, s, ks, vs, B.upos[cur], B.ug[cur], mb, sa, B.v, s_next, d_fu,
                                    B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1], fg_status, B.sc.d_ticket, B.sc.d_err, d_x, d_bwt, d_base, n, b_log);
             ARCHON_HIP_TRY(hipGetLastError());
             ++c->launches;
@@ -416,7 +425,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         ms = c->h_mail[0];
         mb = mb_round ? c->h_mail[2] : 0u;
         bgroups = c->h_mail[3];
-        cs ^= 1;
+        if (!b_only) cs ^= 1;
         uint32_t np = chain ? c->h_mail[4] : 0u;
         const uint32_t pairs_seen = chain ? np : c->h_mail[5];
         if (np) {
@@ -475,6 +484,29 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         }
         ++c->launches;
         trace("scatter_rank");
+    }
+    // Period defects, long groups, before the groups are tied over a whole period (a periodic block enters with h = 3):
+    // certify the groups whose members share a whole period (k_zone_certify) and run the break rounds on those alone --
+    // unless the defects are so many that the byte-by-byte comparisons of the certification would cost more than the rounds.
+    if (m && mb && z_period && h < z_period && (uint64_t)z_breaks * z_period * z_period <= 8ull * n && !route_off(kRtNoBreakRound)) {
+        uint8_t *cert = reinterpret_cast<uint8_t *>(B.rlog);                 // (the S list sits these rounds out: its rank log is idle)
+        uint32_t *okey = B.keep;                                             // (idle until a doubling round lists pairs)
+        ARCHON_HIP_TRY(hipMemsetAsync(cert, 0, n, s));
+        hipLaunchKernelGGL(fwd::k_zone_certify, dim3(div_up(mb, 256)), dim3(256), 0, s, B.ug[cur], B.uitem[cur], mb, sa, B.brk, d_x, n, z_period, cert, okey);
+        ARCHON_HIP_TRY(hipGetLastError());
+        ++c->launches;
+        trace("zone certify");
+        for (bool distance = true;; distance = false) {
+            st.unresolved_total += mb;
+            ++st.break_rounds;
+            const uint32_t before = ms + mb;
+            ARCHON_TRY(do_round(distance ? 2 : 3, z_period, true, cert, okey));
+            const uint32_t settled = before - (ms + mb);
+            st.break_settled += settled;
+            m = ms + mb;
+            trace(distance ? "break round on certified groups (distance)" : "break round on certified groups (continuation)");
+            if (!mb || (!distance && !settled)) break;
+        }
     }
     while (m) {
         // Groups that straddle defects of the period: once every group is tied over a whole period, one round keyed on the

@@ -92,3 +92,49 @@ def test_fuzz_natural_route(archon, oracle, seed):
         sa, bwt, base = archon.forward(x)
         assert (sa == P).all() and (bwt == B).all() and base == b0, (x.size, x[:16], archon.stats())
         assert (archon.inverse(B, b0) == x).all()
+
+
+def defect_case(seed):
+    """a motif of a random period with defects: points, twin defects at one phase, a burst, the first and the last period,
+    a second motif of the same period behind the first, random bytes in front (tools/fuzz_defects.py runs many more seeds)"""
+    rng = np.random.default_rng(1000 + seed)
+    p = int(rng.choice([1, 2, 3, 5, 7, 8, 16, 31, 64, 100, 255, 256, 257, 1000, 1024, 4099, 30000]))
+    n = int(rng.integers(max(4 * p, 5000), 1500000))
+    sigma = int(rng.choice([2, 3, 4, 16, 256]))
+    motif = rng.integers(0, sigma, size=p, dtype=np.uint8)
+    x = np.tile(motif, n // p + 2)[:n].copy()
+    kind = int(rng.integers(0, 6))
+    pos = rng.integers(0, n, size=int(rng.integers(1, 9)))
+    if kind == 1:
+        q = int(rng.integers(0, n // 2))
+        pos = np.array([q, q + p * int(rng.integers(1, max(2, (n - q) // p)))])
+        pos = pos[pos < n]
+    elif kind == 2:
+        q = int(rng.integers(0, n - 10))
+        pos = np.arange(q, q + int(rng.integers(2, 9)))
+    elif kind == 3:
+        pos = np.array([int(rng.integers(0, min(p, n))), n - 1 - int(rng.integers(0, min(p, n)))])
+    for q in pos:
+        x[q] = (int(x[q]) + 1 + int(rng.integers(0, max(1, sigma - 1)))) % sigma
+    if kind == 4:
+        h = int(rng.integers(n // 4, 3 * n // 4))
+        x[h:] = np.tile(rng.integers(0, sigma, size=p, dtype=np.uint8), (n - h) // p + 2)[:n - h]
+    if kind == 5:
+        a = int(rng.integers(0, n // 3))
+        x[:a] = rng.integers(0, 256, size=a, dtype=np.uint8)
+    return np.ascontiguousarray(x, np.uint8)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_period_defects(archon, oracle, seed):
+    """the period-defect rounds (break_key / cont_key / k_zone_certify) on random defect patterns, both first stages"""
+    x = defect_case(seed)
+    P, B, b0 = oracle.forward(x)
+    for path in (None, "0", "1"):
+        if path is not None:
+            os.environ["ARCHON_FORCE_PATH"] = path
+        try:
+            sa, bwt, base = archon.forward(x)
+        finally:
+            os.environ.pop("ARCHON_FORCE_PATH", None)
+        assert (sa == P).all() and (bwt == B).all() and base == b0, (seed, path, x.size)
