@@ -19,10 +19,14 @@ python3 tools/pmc_summary.py $out/pmc > $out/pmc_fetch_write.txt 2>&1
 python3 tools/pmc_traffic.py $out/pmc profiles/$tag/pmc_fetch_write.txt > $out/pmc_traffic.log 2>&1 && cp profiles/pmc_traffic.json $out/pmc_traffic.json
 echo "pmc done"
 timeout -k 10 200 python3 tools/pcie_inclusive.py 256 2>/dev/null | tail -1 > $out/pcie_inclusive.json; cat $out/pcie_inclusive.json
-for sh in random dna text a ab motif prose; do
+for sh in random dna text a ab motif prose motif_defects; do
   timeout -k 10 120 python3 tools/stage_times.py 256 $sh 3 2>/dev/null | tail -1 | sed "s/^/$sh /" >> $out/stage_times.txt || exit 1
 done
 timeout -k 10 120 python3 tools/stage_times.py 256 random 3 inv 2>/dev/null | tail -1 | sed "s/^/inverse-random /" >> $out/stage_times.txt
+# the inverse where T fits the L2 / the memory-side cache (the container's default block is 4 MiB)
+for mib in 4 16 64; do
+  timeout -k 10 120 python3 tools/stage_times.py $mib random 3 inv 2>/dev/null | tail -1 | sed "s/^/inverse-random-${mib}MiB /" >> $out/stage_times.txt
+done
 cat $out/stage_times.txt
 timeout -k 10 600 python3 tools/config5.py 256 2>/dev/null | tail -1 > $out/config5.json && cat $out/config5.json
 timeout -k 10 300 python3 tools/real_text.py 256 2>/dev/null | tail -1 > $out/real_text.json && cat $out/real_text.json
@@ -31,6 +35,9 @@ timeout -k 10 120 python3 tools/radix_dir_bench.py 2>/dev/null | tail -1 > $out/
 bash tools/prof_kernels.sh real > /dev/null 2>&1 && cp gpurun_out/prof_real.txt $out/kernels_real_text.txt
 bash tools/prof_kernels.sh prose > /dev/null 2>&1 && cp gpurun_out/prof_prose.txt $out/kernels_prose.txt
 bash tools/prof_kernels.sh text > /dev/null 2>&1 && cp gpurun_out/prof_text.txt $out/kernels_text.txt
+bash tools/prof_kernels.sh motif_defects > /dev/null 2>&1 && cp gpurun_out/prof_motif_defects.txt $out/kernels_motif_defects.txt
+echo "kernel profiles done"
+timeout -k 10 300 python3 tools/two_ctx.py 256 6 > $out/two_contexts.txt 2>/dev/null; cat $out/two_contexts.txt
 timeout -k 10 200 python3 tools/dup_region.py 256 32 2>/dev/null | tail -1 > $out/dup_region_256_32.json
 timeout -k 10 300 python3 tools/defect_motif.py 80 3 2>/dev/null | tail -1 > $out/defect_motif_80_3.json
 hipcc -O3 --offload-arch=gfx950 -o /tmp/gather_chain tools/micro/gather_chain.hip 2>/dev/null && timeout -k 10 300 /tmp/gather_chain > $out/micro_gather_chain.txt 2>&1

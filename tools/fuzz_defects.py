@@ -31,4 +31,5 @@ for seed in range(s0, s0 + cnt):
             bad += 1
             print("FAIL seed", seed, "route", route or "auto", "n", n, {k2: st.get(k2) for k2 in ("path", "period", "break_rounds", "doubling_rounds")}, flush=True)
     os.environ.pop("ARCHON_FORCE_PATH", None)
+    if (seed - s0) % 20 == 19: print("... seed", seed, "cases", stats["cases"], "failures", bad, flush=True)
 print("cases", stats["cases"], "with break rounds", stats["break_rounds"], "failures:", bad)
