@@ -8,6 +8,7 @@
 #include "rounds.hiph"
 #include "rank_writer.hiph"
 #include "inverse.hiph"
+#include "post.hiph"
 
 #include <stdarg.h>
 #include <atomic>
@@ -1277,6 +1278,76 @@ int archon_hip_sa_to_bwt(const uint8_t *x, uint32_t n, const uint32_t *sa, uint8
     return ARCHON_OK;
 }
 
+// ---- SURVEY 8(f) N4 on the device (post.hiph; parity unpinned -- the host stage host/archon_post.cpp states the format)
+static int post_run(Ctx *c, hipStream_t s, const uint8_t *d_bwt, uint32_t n, uint8_t *d_out, size_t *out_bytes)
+{
+    const uint32_t np = post::pieces_of(n);
+    if (np == 0) {                                   // an empty block: u32 pieces = 0
+        ARCHON_HIP_TRY(hipMemsetAsync(d_out, 0, 4, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        *out_bytes = 4;
+        return ARCHON_OK;
+    }
+    ARCHON_TRY(ctx_ensure_arena(c, (size_t)np * post::kSlotBytes + 4 * (size_t)np + 4096));
+    c->arena_reset();
+    uint8_t *slots = c->alloc<uint8_t>((size_t)np * post::kSlotBytes);
+    uint32_t *sizes = c->alloc<uint32_t>(np);
+    unsigned long long *d_total = reinterpret_cast<unsigned long long *>(c->d_mail + 630);
+    if (!slots || !sizes) { set_error("arena exhausted"); return ARCHON_E_NOMEM; }
+    hipLaunchKernelGGL(post::k_post_piece, dim3(np), dim3(post::kLanes), 0, s, d_bwt, n, slots, sizes);
+    hipLaunchKernelGGL(post::k_post_gather, dim3(np), dim3(256), 0, s, slots, sizes, np, d_out, d_total);
+    ARCHON_HIP_TRY(hipGetLastError());
+    ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 630, d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    unsigned long long total;
+    memcpy(&total, c->h_mail + 630, sizeof total);
+    if (total < 4 + 4ull * np || total > post::block_bound(n)) { set_error("post stage: stream length %llu out of bounds", total); return ARCHON_E_INTERNAL; }
+    *out_bytes = (size_t)total;
+    c->launches += 2;
+    return ARCHON_OK;
+}
+
+size_t archon_hip_post_bound(uint32_t n) { return post::block_bound(n); }
+
+int archon_hip_post_encode_dev(const uint8_t *d_bwt, uint32_t n, uint8_t *d_out, size_t cap, size_t *out_bytes, int dev, void *stream)
+{
+    if ((!d_bwt && n) || !d_out || !out_bytes) { set_error("null pointer"); return ARCHON_E_ARG; }
+    if (n > ARCHON_HIP_MAX_N) { set_error("block size %u out of range [0, %u]", n, ARCHON_HIP_MAX_N); return ARCHON_E_ARG; }
+    if (cap < post::block_bound(n)) { set_error("post stage: output buffer of %zu bytes, %zu needed (archon_hip_post_bound)", cap, post::block_bound(n)); return ARCHON_E_ARG; }
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+    return post_run(c, s, d_bwt, n, d_out, out_bytes);
+}
+
+int archon_hip_forward_post(const uint8_t *x, uint32_t n, uint8_t *out, size_t cap, size_t *out_bytes, uint32_t *base_id, int dev)
+{
+    if (!x || !out || !out_bytes || !base_id) { set_error("null pointer"); return ARCHON_E_ARG; }
+    ARCHON_TRY(check_n(n));
+    if (cap < post::block_bound(n)) { set_error("post stage: output buffer of %zu bytes, %zu needed (archon_hip_post_bound)", cap, post::block_bound(n)); return ARCHON_E_ARG; }
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = c->own_stream;
+    uint8_t *d_x = nullptr, *d_bwt = nullptr, *d_pk = nullptr;
+    ARCHON_TRY(ctx_io(c, 0, (size_t)n + 64, (void **)&d_x));
+    ARCHON_TRY(ctx_io(c, 1, (size_t)n + 64, (void **)&d_bwt));
+    ARCHON_TRY(ctx_io(c, 2, post::block_bound(n) + 64, (void **)&d_pk));
+    c->keep_bwt = nullptr; c->keep_n = 0;
+    uint32_t *d_base = c->d_mail + 620;
+    ARCHON_HIP_TRY(hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s));
+    ARCHON_TRY(forward_run(c, s, d_x, n, nullptr, d_bwt, d_base));
+    ARCHON_TRY(post_run(c, s, d_bwt, n, d_pk, out_bytes));
+    // only the packed stream crosses the link
+    ARCHON_HIP_TRY(hipMemcpyAsync(out, d_pk, *out_bytes, hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipMemcpyAsync(base_id, d_base, 4, hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    return ARCHON_OK;
+}
+
 static int lms_select_run(Ctx *c, hipStream_t s, const uint8_t *d_x, uint32_t n, uint32_t *d_count, uint32_t *d_items, uint32_t *n1_out)
 {
     ARCHON_TRY(ctx_ensure_arena(c, forward_arena_bytes(n)));
@@ -1447,6 +1518,14 @@ int archon_hip_exp_stamps(unsigned long long out[64])
 int archon_hip_exp_ls_stamps(unsigned long long out[16])
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(bs::g_ls_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? ARCHON_OK : ARCHON_E_HIP;
+}
+#endif
+
+#ifdef ARCHON_EXPERIMENTS
+/* cycle stamps of the middle workgroup of the last k_post_piece launch */
+int archon_hip_exp_post_stamps(unsigned long long out[16])
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(post::g_post_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? ARCHON_OK : ARCHON_E_HIP;
 }
 #endif
 

@@ -43,6 +43,7 @@ struct Slot {
     byte *in = nullptr, *out = nullptr;
     bool pinned = false;
     size_t n = 0;            // payload bytes of the block in the slot
+    size_t packed = 0;       // post stage: bytes of the packed stream in `out`
     t_index base = 0;
     SlotState state = kFree;
     bool last = false;
@@ -55,18 +56,19 @@ struct Pipe {
     long nblocks = -1;       // known once the reader has seen the short block
     int rc = 0;              // first error; everybody stops
 
-    bool alloc(int nslots, size_t bytes)
+    bool alloc(int nslots, size_t bytes, size_t out_bytes = 0)
     {
+        if (!out_bytes) out_bytes = bytes;
         slot.resize(nslots);
         for (Slot &s : slot) {
             s.in = static_cast<byte *>(archon_hip_host_alloc(bytes));
-            s.out = static_cast<byte *>(archon_hip_host_alloc(bytes));
+            s.out = static_cast<byte *>(archon_hip_host_alloc(out_bytes));
             s.pinned = s.in && s.out;
             if (!s.pinned) {
                 if (s.in) archon_hip_host_free(s.in);
                 if (s.out) archon_hip_host_free(s.out);
                 s.in = static_cast<byte *>(malloc(bytes));
-                s.out = static_cast<byte *>(malloc(bytes));
+                s.out = static_cast<byte *>(malloc(out_bytes));
             }
             if (!s.in || !s.out) return false;
         }
@@ -124,39 +126,12 @@ void worker_loop(Pipe &p, int first, int step, int dev, Work work)
     }
 }
 
-// ---- post stage (no reference implementation): a block's BWT is cut into pieces of 4 MiB that are
-// coded independently (MTF restarts per piece) by a pool of host threads.
+// ---- post stage (no reference implementation): a block's BWT is cut into pieces of 32 KiB that are
+// coded independently (MTF restarts per piece, archon_post.cpp).  Encoding runs on the GPU behind the transform
+// (archon_hip_forward_post: one workgroup per piece, only the packed stream comes back over the link); decoding is a pool
+// of host threads.
 // Packed block: u32 pieces | u32 packed bytes of each piece | the pieces.
-constexpr size_t kPiece = 4u << 20;
-
-void post_pack(const byte *bwt, size_t n, std::vector<byte> &out)
-{
-    const size_t np = (n + kPiece - 1) / kPiece;
-    std::vector<std::vector<byte>> part(np);
-    std::vector<std::thread> th;
-    const unsigned nth = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 32u));
-    for (unsigned t = 0; t < nth; ++t)
-        th.emplace_back([&, t] {
-            for (size_t k = t; k < np; k += nth) {
-                const size_t len = std::min(kPiece, n - k * kPiece);
-                part[k].resize(archon_post_bound(len));
-                part[k].resize(archon_post_encode(bwt + k * kPiece, len, part[k].data()));
-            }
-        });
-    for (auto &t : th) t.join();
-    size_t total = 4 + 4 * np;
-    for (auto &v : part) total += v.size();
-    out.resize(total);
-    const uint32_t np32 = (uint32_t)np;
-    memcpy(out.data(), &np32, 4);
-    size_t off = 4 + 4 * np;
-    for (size_t k = 0; k < np; ++k) {
-        const uint32_t sz = (uint32_t)part[k].size();
-        memcpy(out.data() + 4 + 4 * k, &sz, 4);
-        memcpy(out.data() + off, part[k].data(), sz);
-        off += sz;
-    }
-}
+constexpr size_t kPiece = 32u << 10;
 
 // returns the block length n, or -1 on a malformed stream; bwt must hold `cap` bytes
 long post_unpack(const byte *in, size_t in_bytes, byte *bwt, size_t cap)
@@ -201,7 +176,8 @@ int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev, int po
     if (ndev < 1) return -4;
     if (fwrite(post ? &kSigPost : &kSig, 2, 1, fo) != 1 || fwrite(&bsize, 4, 1, fo) != 1) return -3;     // (a full disk shows here first)
     Pipe p;
-    if (!p.alloc((kWorkersPerGpu + 2) * ndev, (size_t)bsize + 4)) return ARCHON_E_NOMEM;
+    const size_t out_cap = post ? archon_hip_post_bound(bsize) + 4 : (size_t)bsize + 4;
+    if (!p.alloc((kWorkersPerGpu + 2) * ndev, (size_t)bsize + 4, out_cap)) return ARCHON_E_NOMEM;
 
     std::thread reader([&] {
         for (long b = 0;; ++b) {
@@ -217,7 +193,8 @@ int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev, int po
     std::vector<std::thread> workers;
     for (int w = 0; w < kWorkersPerGpu * ndev; ++w)
         workers.emplace_back([&, w] {
-            worker_loop(p, w, kWorkersPerGpu * ndev, w % ndev, [](Slot &s, int dev) {
+            worker_loop(p, w, kWorkersPerGpu * ndev, w % ndev, [post, out_cap](Slot &s, int dev) {
+                if (post) return archon_hip_forward_post(s.in, (uint32_t)s.n, s.out, out_cap, &s.packed, &s.base, dev);
                 return archon_hip_forward(s.in, (uint32_t)s.n, NULL, s.out, &s.base, dev);
             });
         });
@@ -226,10 +203,10 @@ int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev, int po
             Slot *s;
             if (!p.wait(b, kDone, &s)) return;
             if (post) {                                  // u32 packed bytes | packed block | index
-                std::vector<byte> packed;
-                post_pack(s->out, s->n, packed);
-                const uint32_t sz = (uint32_t)packed.size();
-                if (fwrite(&sz, 4, 1, fo) != 1 || fwrite(packed.data(), 1, sz, fo) != sz) { p.fail(-3); return; }
+                static const byte kEmpty[4] = {0, 0, 0, 0};             // an empty last block: zero pieces
+                const byte *pk = s->n ? s->out : kEmpty;
+                const uint32_t sz = s->n ? (uint32_t)s->packed : 4u;
+                if (fwrite(&sz, 4, 1, fo) != 1 || fwrite(pk, 1, sz, fo) != sz) { p.fail(-3); return; }
             } else if (s->n && fwrite(s->out, 1, s->n, fo) != s->n) { p.fail(-3); return; }
             const t_index base = s->n ? s->base : 0;
             if (fwrite(&base, 4, 1, fo) != 1) { p.fail(-3); return; }
@@ -260,7 +237,7 @@ int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out)
             if (!p.wait(b, kFree, &s)) return;
             if (post) {
                 uint32_t sz = 0;
-                if (fread(&sz, 4, 1, fi) != 1 || sz > archon_post_bound(bsize) + 4 * (bsize / kPiece + 2)) { p.fail(-2); return; }
+                if (fread(&sz, 4, 1, fi) != 1 || sz > 4 + ((size_t)bsize / kPiece + 1) * (4 + archon_post_bound(kPiece))) { p.fail(-2); return; }
                 std::vector<byte> packed(sz);
                 if (fread(packed.data(), 1, sz, fi) != sz || fread(&s->base, 4, 1, fi) != 1) { p.fail(-2); return; }
                 const long n = post_unpack(packed.data(), sz, s->in, bsize);

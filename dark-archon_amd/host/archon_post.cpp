@@ -7,7 +7,10 @@
 // coder.  This is a self-consistent host-side stage (round-trip tested only); it is not part of the BWT hot path
 // and not a fallback for it: the transform itself still runs on the GPU or fails.
 //
-// Stream of one block:  u32 n | u8 code length of each of the 258 symbols | bit stream (LSB first).
+// Stream of one piece (the container cuts a block into pieces of 32 KiB, archon_container.cpp):
+//   u32 n | u8 code length of each of the 258 symbols | bit stream (LSB first).
+// The container's encoder runs this stage on the GPU (csrc/post.hiph, archon_hip_forward_post): same bytes; this file is
+// the statement of the format, the decoder, and what tests/test_gpu_post.py holds the device stage against.
 // Symbols: 0 = RUNA, 1 = RUNB (a run of r zeros after MTF is written as the bijective base-2 digits of r, as in
 // bzip2), 2..256 = MTF value 1..255, 257 = end of block.
 #include <stdint.h>
@@ -117,7 +120,9 @@ void mtf_rle(const uint8_t *bwt, size_t n, Emit emit)
 
 extern "C" {
 
-size_t archon_post_bound(size_t n) { return n + n / 2 + 1024; }
+// the longest stream n bytes can make: every position one symbol of kMaxLen bits, plus the end symbol (the same figure
+// the device stage sizes its piece slots by, csrc/post.hiph)
+size_t archon_post_bound(size_t n) { return 4 + (size_t)kSyms + ((n + 1) * kMaxLen + 7) / 8 + 8; }
 
 size_t archon_post_encode(const uint8_t *bwt, size_t n, uint8_t *out)
 {

@@ -125,6 +125,17 @@ int archon_hip_reserve(uint32_t n, int dev, size_t *bytes_or_null);
 /* Free the per-device context (arena, streams, events). */
 int archon_hip_release(int dev);
 
+/* ---- the MTF + zero-run + order-0 Huffman stage of the container's `-m` blocks, on the device --------
+ * PARITY UNPINNED: the reference has no such stage (kvark/dark-archon README.md:2 only promises "compression schemes
+ * eventually"); dark-archon_amd/host/archon_post.cpp states the format, these entry points produce the same bytes.
+ * Stream of a block: u32 pieces | u32 bytes of each piece | the pieces; a piece codes 32 KiB of the BWT:
+ * u32 n | 258 code lengths | bits (LSB first). */
+size_t archon_hip_post_bound(uint32_t n);      /* bytes the stream of an n-byte block can take at most */
+/* BWT on the device -> its stream on the device; *out_bytes = the stream's length (returned after a stream sync) */
+int archon_hip_post_encode_dev(const uint8_t *d_bwt, uint32_t n, uint8_t *d_out, size_t cap, size_t *out_bytes, int dev, void *stream);
+/* host block -> forward BWT -> stream, host buffers: only the packed stream and the primary index come back over the link */
+int archon_hip_forward_post(const uint8_t *x, uint32_t n, uint8_t *out, size_t cap, size_t *out_bytes, uint32_t *base_id, int dev);
+
 /* ---- measurement ------------------------------------------------------------- */
 
 /* Per-stage device times (HIP events on the stream the kernels ran on) and
