@@ -195,7 +195,8 @@ struct FwdBuf {
 // shortcut for periodic blocks, text rounds, the rank table, doubling rounds with the pair chains.  Rows take their
 // BWT symbol when they become final.
 static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, uint32_t n, uint32_t *sa, uint32_t h0,
-                         uint8_t *d_bwt, uint32_t *d_base, archon_hip_stats &st, uint32_t p_hint, bool ws_ready, bool deep_ties)
+                         uint8_t *d_bwt, uint32_t *d_base, archon_hip_stats &st, uint32_t p_hint, bool ws_ready, bool deep_ties,
+                         bool brk_ready /*B.brk holds the break table of period p_hint*/, uint32_t p_breaks /*... which has that many breaks*/)
 {
     const uint32_t g256 = div_up(n, 256);
 #ifdef ARCHON_EXPERIMENTS
@@ -230,7 +231,13 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     // settle the periodic runs directly (forward.hiph, k_chain_*) before any doubling round
     // (long duplicates without a period -- deep_ties and no period probe -- are pairs: the pair chains of the rounds settle
     //  them with less per-group work than this shortcut spends on millions of two-row groups)
-    if (m >= n / 16 && !(deep_ties && p_hint == 0) && !route_off(kRtNoChains)) {
+    if (brk_ready && p_breaks && m) {
+        // the period is known and the text breaks it somewhere: the tied groups straddle the defects, none of them is one clean
+        // run -- the run shortcut would look at every row and settle nothing; the period-defect rounds below take all of it
+        z_period = p_hint;
+        z_breaks = p_breaks;
+        st.period = p_hint;
+    } else if (m >= n / 16 && !(deep_ties && p_hint == 0) && !route_off(kRtNoChains)) {
         uint32_t p = p_hint;
         bool dominant = p_hint != 0;        // the driver's period probe already named the period (and the groups may be unordered)
         if (!dominant) {
@@ -253,9 +260,11 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             uint32_t *brk = B.brk, *ginfo = B.dst, *gend = B.keep, *settled = B.small + 601;
             uint32_t *gmin = B.ug[1], *gmax = B.uitem[1];       // the second triple buffers are idle
             uint32_t *d_lastbrk = B.small + 606;
-            ARCHON_HIP_TRY(hipMemsetAsync(d_lastbrk, 0, 2 * sizeof(uint32_t), s));      // [0] last real break, [1] how many
-            hipLaunchKernelGGL(fwd::k_period_breaks, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, p, brk, d_lastbrk);
-            ARCHON_TRY(launch_scan<1>(s, brk, brk, n, B.scan_tmp, nullptr));
+            if (!(brk_ready && p == p_hint)) {
+                ARCHON_HIP_TRY(hipMemsetAsync(d_lastbrk, 0, 2 * sizeof(uint32_t), s));  // [0] last real break, [1] how many
+                hipLaunchKernelGGL(fwd::k_period_breaks, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, p, brk, d_lastbrk);
+                ARCHON_TRY(launch_scan<1>(s, brk, brk, n, B.scan_tmp, nullptr));
+            }
             hipLaunchKernelGGL(fwd::k_chain_init, dim3(g256), dim3(256), 0, s, B.v, n, gmin, gmax, ginfo);
             ARCHON_HIP_TRY(hipMemsetAsync(settled, 0, sizeof(uint32_t), s));
             trace("breaks + scan + memsets");
@@ -864,6 +873,22 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             }
         }
     }
+    // A block with a period: where does the text break it?  (The table serves the run shortcut; a block WITH breaks skips the
+    // shortcut -- its groups straddle the defects -- gets its tied rows listed by the entry sweep and goes to the
+    // period-defect rounds.)
+    bool brk_ready = false;
+    uint32_t period_breaks = 0;
+    if (period_hint && !route_off(kRtNoChains)) {
+        uint32_t *d_lastbrk = small + 606;
+        ARCHON_HIP_TRY(hipMemsetAsync(d_lastbrk, 0, 2 * sizeof(uint32_t), s));          // [0] last real break, [1] how many
+        hipLaunchKernelGGL(fwd::k_period_breaks, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, period_hint, B.brk, d_lastbrk);
+        ARCHON_TRY(launch_scan<1>(s, B.brk, B.brk, n, B.scan_tmp, nullptr));
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 2, d_lastbrk + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        c->launches += 4;
+        brk_ready = true;
+        period_breaks = route_off(kRtNoBreakRound) ? 0u : c->h_mail[2];
+    }
     if (path == 0) {
         // heavily skewed at two bytes.  Alphabet compaction: with <= 16 distinct bytes a key
         // byte holds 2, 4 or 8 symbols; if the two-byte buckets of THAT text are small enough the block still
@@ -918,7 +943,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, &d_ctl->base_id, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         } else {
             h0 = (h_ctl.min_depth < 5 ? h_ctl.min_depth : 5) * (uint32_t)Q;     // key bytes -> symbols
-            ws_ready = period_hint == 0;
+            ws_ready = period_hint == 0 || period_breaks != 0;
             ARCHON_TRY(first_groups(1, nullptr, nullptr, 0, ws_ready));
             ARCHON_HIP_TRY(hipMemcpyAsync(d_base, &d_ctl->base_id, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         }
@@ -971,7 +996,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         uint64_t *kS = in_b ? B.keyB : B.keyA;
         uint32_t *vS = in_b ? B.valB : B.valA;
         e2 = tm.mark();
-        ws_ready = key_bytes == fwd::kKeyBytes;          // a periodic block: the run shortcut will empty the working set
+        ws_ready = key_bytes == fwd::kKeyBytes || period_breaks != 0;     // a clean periodic block: the run shortcut will empty the working set
         ARCHON_TRY(first_groups(0, kS, vS, 8u * (8u - key_bytes), ws_ready));
         e3 = e2;
     }
@@ -983,7 +1008,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         const bool deep_ties = path == 1 && big_items == 0 && h_ctl.min_depth >= 5 && !route_off(kRtNoDeepHint) &&
                                (listed_all ? (uint64_t)h_ctl.unresolved * 64 >= n
                                            : (uint64_t)h_ctl.unresolved * 2 >= bs::kTieSample && (uint64_t)h_ctl.tie_items * 64 >= n);
-        ARCHON_TRY(general_stage(c, s, B, d_x, n, sa, h0, d_bwt, d_base, st, period_hint, ws_ready, deep_ties));
+        ARCHON_TRY(general_stage(c, s, B, d_x, n, sa, h0, d_bwt, d_base, st, period_hint, ws_ready, deep_ties, brk_ready, period_breaks));
         e4 = tm.mark();
         ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, d_base, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
