@@ -1,7 +1,8 @@
 """BASELINE.json configs[4]: a 1 GiB mixed corpus (4 x 256 MiB: text, random, DNA, 1000-byte motif repeated) through
 the CLI's multi-block container: `archon e -b256m`, `archon d -b`, byte compare; plus the device-side times of each
-block's forward and inverse through the C ABI.  (The "MTF/entropy stage" of that config has no reference
-implementation: SURVEY.md 8(f) N4.)  Usage: python tools/config5.py [block MiB]"""
+block's forward and inverse through the C ABI; then the same corpus through `archon e -m` (the config's "MTF/entropy
+stage": no reference implementation, SURVEY.md 8(f) N4 -- on the GPU behind the transform) and back.
+Usage: python tools/config5.py [block MiB]"""
 import hashlib, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dark-archon_amd"))
@@ -42,9 +43,18 @@ def sha(p):
 res["cli_round_trip_identical"] = sha(tmp + ".in") == sha(tmp + ".out")
 res["cli_encode_wall_s"] = round(t1 - t0, 2); res["cli_decode_wall_s"] = round(t2 - t1, 2)
 res["container_bytes"] = os.path.getsize(tmp + ".ra")
+# the same corpus with the MTF + zero-run + Huffman stage (`-m`; on the GPU behind the transform, csrc/post.hiph; decoded by host threads)
+t0 = time.time(); r = subprocess.run([exe, "e", "-m", "-b%dm" % mib, tmp + ".in", tmp + ".rm"], capture_output=True, text=True); t1 = time.time()
+assert r.returncode == 0, r.stdout + r.stderr
+r = subprocess.run([exe, "d", "-b", tmp + ".rm", tmp + ".out2"], capture_output=True, text=True); t2 = time.time()
+assert r.returncode == 0, r.stdout + r.stderr
+res["post_round_trip_identical"] = sha(tmp + ".in") == sha(tmp + ".out2")
+res["post_encode_wall_s"] = round(t1 - t0, 2); res["post_decode_wall_s"] = round(t2 - t1, 2)
+res["post_container_bytes"] = os.path.getsize(tmp + ".rm")
+os.remove(tmp + ".rm"); os.remove(tmp + ".out2")
 res["device_forward_ms_total"] = round(sum(b["forward_ms"] for b in res["blocks"]), 2)
 res["device_inverse_ms_total"] = round(sum(b["inverse_ms"] for b in res["blocks"]), 2)
 for ext in (".in", ".ra", ".out"):
     os.remove(tmp + ext)
 print(json.dumps(res))
-assert res["cli_round_trip_identical"]
+assert res["cli_round_trip_identical"] and res["post_round_trip_identical"]
