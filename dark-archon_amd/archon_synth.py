@@ -192,7 +192,16 @@ def gen_motif_defects(n, motif_len=4099, defects=5, seed=SEED_BASE + 7):
     return x
 
 
-SHAPES = ("text", "random", "dna", "a", "ab", "motif", "prose", "motif_defects")
+def gen_random_copy(n, seed=SEED_BASE + 8):
+    """a long non-periodic duplicate: uniform random bytes with the first n/8 bytes copied to the middle of the block -- every
+    item inside the copy is tied with its twin far beyond any first stage (tools/dup_region.py; the pair chains' regime)"""
+    x = gen_random(n, seed).copy()
+    L = n // 8
+    x[n // 2:n // 2 + L] = x[:L]
+    return x
+
+
+SHAPES = ("text", "random", "dna", "a", "ab", "motif", "prose", "motif_defects", "random_copy")
 
 
 def gen_shape(shape, n, block=0):
@@ -213,4 +222,6 @@ def gen_shape(shape, n, block=0):
         return gen_prose(n, SEED_BASE + 6 + block)
     if shape == "motif_defects":
         return gen_motif_defects(n, 4099, 5, SEED_BASE + 7 + block)
+    if shape == "random_copy":
+        return gen_random_copy(n, SEED_BASE + 8 + block)
     raise ValueError(shape)

@@ -28,7 +28,7 @@ import oracle_binding as OB  # noqa: E402
 
 SMALL = [257]
 HASHED = [65536, 1 << 20]
-BIG = {"random": 1 << 24, "dna": 1 << 24, "text": 1 << 24, "prose": 1 << 24, "motif_defects": 1 << 24}
+BIG = {"random": 1 << 24, "dna": 1 << 24, "text": 1 << 24, "prose": 1 << 24, "motif_defects": 1 << 24, "random_copy": 1 << 24}
 
 
 def digest(P, bwt, base):

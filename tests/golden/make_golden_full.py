@@ -31,7 +31,7 @@ import oracle_binding as OB  # noqa: E402
 N = 256 << 20
 # (shape, block): bench.py seeds rank r's block with block=r, configs[3] is 8 DNA blocks
 CASES = ([("random", b) for b in range(8)] + [("dna", b) for b in range(8)] +
-         [("text", 0), ("a", 0), ("ab", 0), ("motif", 0), ("prose", 0), ("motif_defects", 0)])
+         [("text", 0), ("a", 0), ("ab", 0), ("motif", 0), ("prose", 0), ("motif_defects", 0), ("random_copy", 0)])
 PART_DIR = os.path.join(HERE, "_full_parts")
 
 
@@ -48,7 +48,7 @@ def run_case(shape, block):
     t0 = time.time()
     # shipped a7 first; it crashes or fails its own validate() on the no-LMS / repetitive shapes
     res, who = None, None
-    if shape in ("random", "dna", "text", "prose", "motif_defects"):
+    if shape in ("random", "dna", "text", "prose", "motif_defects", "random_copy"):
         res = OB.run_ref(x, "a7ref")
         who = "a7ref"
         shipped = "crash" if res is None else ("ok" if res["validate"] == 1 else "fails_own_validate")

@@ -19,7 +19,7 @@ python3 tools/pmc_summary.py $out/pmc > $out/pmc_fetch_write.txt 2>&1
 python3 tools/pmc_traffic.py $out/pmc profiles/$tag/pmc_fetch_write.txt > $out/pmc_traffic.log 2>&1 && cp profiles/pmc_traffic.json $out/pmc_traffic.json
 echo "pmc done"
 timeout -k 10 200 python3 tools/pcie_inclusive.py 256 2>/dev/null | tail -1 > $out/pcie_inclusive.json; cat $out/pcie_inclusive.json
-for sh in random dna text a ab motif prose motif_defects; do
+for sh in random dna text a ab motif prose motif_defects random_copy; do
   timeout -k 10 120 python3 tools/stage_times.py 256 $sh 3 2>/dev/null | tail -1 | sed "s/^/$sh /" >> $out/stage_times.txt || exit 1
 done
 timeout -k 10 120 python3 tools/stage_times.py 256 random 3 inv 2>/dev/null | tail -1 | sed "s/^/inverse-random /" >> $out/stage_times.txt
