@@ -71,3 +71,21 @@ def test_hip_vs_reference_full_size(archon, case):
     del out
     sa = sa_t.cpu().numpy()
     assert _sha(sa) == case["sha256_P"]
+
+
+@pytest.mark.parametrize("shape,route", [("random", "0"), ("text", "1"), ("prose", "1"), ("motif_defects", "1")])
+def test_hip_vs_reference_full_size_other_route(archon, shape, route, monkeypatch):
+    """the full-size reference digests again with the first stage the block would NOT take by itself: the 7-pass route on
+    the uniform random block (ARCHON_FORCE_PATH=0), the streaming stage -- oversized two-byte buckets handed on as groups tied
+    over two bytes -- on the skewed ones (=1): every route gives the reference's bytes at the graded size, not only at n / 8"""
+    import torch
+    case = [c for c in GOLDEN_FULL["cases"] if c["shape"] == shape and c["block"] == 0][0]
+    monkeypatch.setenv("ARCHON_FORCE_PATH", route)
+    n = case["n"]
+    x_t = torch.from_numpy(S.gen_shape(shape, n, block=0)).cuda()
+    sa_t = torch.empty(n, dtype=torch.int32, device="cuda")
+    out_t = torch.empty(n + 4, dtype=torch.uint8, device="cuda")
+    archon.forward_dev(x_t, sa_t, out_t[:n], out_t[n:].view(torch.int32))
+    assert archon.stats()["path"] == int(route)
+    assert _sha(out_t.cpu().numpy()) == case["sha256_bwt_base"]
+    assert _sha(sa_t.cpu().numpy()) == case["sha256_P"]
