@@ -73,11 +73,13 @@ def test_hip_vs_reference_full_size(archon, case):
     assert _sha(sa) == case["sha256_P"]
 
 
-@pytest.mark.parametrize("shape,route", [("random", "0"), ("text", "1"), ("prose", "1"), ("motif_defects", "1")])
+@pytest.mark.parametrize("shape,route", [("random", "0"), ("dna", "0"), ("a", "0"), ("ab", "0"), ("random_copy", "0"),
+                                         ("text", "1"), ("prose", "1"), ("motif", "1"), ("motif_defects", "1")])
 def test_hip_vs_reference_full_size_other_route(archon, shape, route, monkeypatch):
     """the full-size reference digests again with the first stage the block would NOT take by itself: the 7-pass route on
-    the uniform random block (ARCHON_FORCE_PATH=0), the streaming stage -- oversized two-byte buckets handed on as groups tied
-    over two bytes -- on the skewed ones (=1): every route gives the reference's bytes at the graded size, not only at n / 8"""
+    the blocks that stream by themselves (ARCHON_FORCE_PATH=0: random, DNA on packed keys, the periodic ones, the block with a
+    long copy), the streaming stage -- oversized two-byte buckets handed on as groups tied over two bytes -- on the skewed
+    ones (=1): every route gives the reference's bytes at the graded size, not only at n / 8"""
     import torch
     case = [c for c in GOLDEN_FULL["cases"] if c["shape"] == shape and c["block"] == 0][0]
     monkeypatch.setenv("ARCHON_FORCE_PATH", route)
