@@ -59,6 +59,12 @@ class ArchonError(RuntimeError):
 def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libarchon_hip.so not built: run `make lib` (hipcc, gfx950); there is no CPU fallback")
+    # A process that also uses PyTorch-ROCm must load torch FIRST: torch brings its own HIP runtime, and a library that has
+    # already bound to the system's runtime then finds no device ("no HIP device available") once torch has opened the GPU.
+    import importlib.util
+    import sys
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     vp, u32, i32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_size_t
     lib.archon_hip_device_count.restype = i32
@@ -81,10 +87,14 @@ def load():
         "archon_hip_reserve": [u32, i32, vp],
         "archon_hip_release": [i32],
         "archon_hip_get_stats": [i32, ctypes.POINTER(Stats)],
+        "archon_hip_post_encode_dev": [vp, u32, vp, sz, vp, i32, vp],
+        "archon_hip_forward_post": [vp, u32, vp, sz, vp, vp, i32],
     }.items():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = i32
+    lib.archon_hip_post_bound.argtypes = [u32]
+    lib.archon_hip_post_bound.restype = sz
     lib.archon_hip_test_route.argtypes = [ctypes.c_char_p, ctypes.c_long]      # include/archon_hip_test.h (tests only)
     lib.archon_hip_test_route.restype = i32
     return lib
