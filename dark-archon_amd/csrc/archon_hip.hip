@@ -502,7 +502,8 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         uint8_t *cert = reinterpret_cast<uint8_t *>(B.rlog);                 // (the S list sits these rounds out: its rank log is idle)
         uint32_t *okey = B.keep;                                             // (idle until a doubling round lists pairs)
         ARCHON_HIP_TRY(hipMemsetAsync(cert, 0, n, s));
-        hipLaunchKernelGGL(fwd::k_zone_certify, dim3(div_up(mb, 256)), dim3(256), 0, s, B.ug[cur], B.uitem[cur], mb, sa, B.brk, d_x, n, z_period, cert, okey);
+        ARCHON_HIP_TRY(hipMemsetAsync(okey, 0, (size_t)n * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(fwd::k_zone_certify, dim3(g256), dim3(256), 0, s, B.rank, sa, B.brk, d_x, n, z_period, cert, okey);
         ARCHON_HIP_TRY(hipGetLastError());
         ++c->launches;
         trace("zone certify");
