@@ -21,9 +21,11 @@
  *
  * Error model: 0 = ok, negative = ARCHON_E_* below (the reference returns int
  * from every Archon method, archon.h:16-28).  The library owns device memory and
- * streams (one context per device, created lazily, serialised by a per-device
- * mutex so separate host threads may drive separate devices concurrently);
- * callers own every buffer they pass.  There is NO CPU fallback: without a HIP
+ * streams: two contexts per device (arena, staging buffers, stream each), created
+ * lazily; a host thread is bound to one of them at its first call, so one thread sees
+ * strictly serial behaviour and two threads feeding one GPU overlap one block's copies
+ * with the other's kernels; separate devices run concurrently.  Callers own every
+ * buffer they pass.  There is NO CPU fallback: without a HIP
  * device every compute entry point returns ARCHON_E_NODEVICE.
  *
  * Limits: 1 <= n <= ARCHON_HIP_MAX_N (the reference needs n < 2^30 for its
@@ -118,11 +120,11 @@ int archon_hip_lms_select_dev(const uint8_t *d_x, uint32_t n, uint32_t *d_count2
 
 /* ---- workspace / lifetime ---------------------------------------------------- */
 
-/* Pre-size the per-device arena for blocks up to n bytes (optional; the arena
- * grows on demand).  Returns bytes reserved via *bytes_or_null. */
+/* Pre-size the arena of the calling thread's context for blocks up to n bytes (optional;
+ * the arena grows on demand).  Returns bytes reserved via *bytes_or_null. */
 int archon_hip_reserve(uint32_t n, int dev, size_t *bytes_or_null);
 
-/* Free the per-device context (arena, streams, events). */
+/* Free the device's contexts (arenas, staging buffers, streams, events). */
 int archon_hip_release(int dev);
 
 /* ---- the MTF + zero-run + order-0 Huffman stage of the container's `-m` blocks, on the device --------
