@@ -194,10 +194,7 @@ def main():
         out_t = pipe.next_buffer()
         # baseId lands behind the BWT: BWT || baseId (LE); n is a multiple of 4, the view is aligned
         pyarchon.forward_dev(x_t, sa_t, out_t[:n], out_t[n:].view(torch.int32))
-        st = pyarchon.stats(local_rank)
-        pass_ms.append(st["ms_radix_pass_sum"])
-        pass_cnt.append(st["radix_pass_timed"])
-        stage.append(st)
+        stage.append(pyarchon.stats_raw(local_rank))      # (the structure as it is: turned into dicts behind the timed region)
         pipe.submit()
 
     def fence():
@@ -215,6 +212,9 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    stage[:] = [s.asdict() for s in stage]
+    pass_ms[:] = [s["ms_radix_pass_sum"] for s in stage]
+    pass_cnt[:] = [s["radix_pass_timed"] for s in stage]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

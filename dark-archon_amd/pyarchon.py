@@ -212,9 +212,14 @@ def radix_scatter(src, dev=0):
 
 
 def stats(dev=0):
+    return stats_raw(dev).asdict()
+
+
+def stats_raw(dev=0):
+    """the Stats structure itself (asdict() later): what a timed loop takes per step"""
     s = Stats()
-    _check(lib().archon_hip_get_stats(dev, ctypes.byref(s)))
-    return s.asdict()
+    _check(_lib.archon_hip_get_stats(dev, ctypes.byref(s)) if _lib is not None else lib().archon_hip_get_stats(dev, ctypes.byref(s)))
+    return s
 
 
 def reserve(n, dev=0):
