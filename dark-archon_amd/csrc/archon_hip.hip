@@ -41,14 +41,35 @@ static constexpr int kMaxDev = 64, kCtxPerDev = 2;
 static constexpr uint32_t kTieListCap = 1u << 20;
 static Ctx *g_ctx[kMaxDev][kCtxPerDev];
 static std::mutex g_ctx_mu;
-static std::atomic<unsigned> g_next_slot{0};
+// The binding is per (thread, device): the k-th thread that comes to device d takes context k mod 2 OF THAT DEVICE (one
+// process-wide counter would hand the two workers of a GPU the same context on every node with an even number of GPUs),
+// or the context it asked for by name (archon_hip_bind_context: the container's worker w of GPU d asks for context w / G).
+static std::atomic<unsigned> g_next_slot[kMaxDev];
+static thread_local signed char t_slot[kMaxDev];      // 0: not bound yet; else slot + 1
+// the statistics of the calling thread's last transform on a device (archon_hip_get_stats): kept per thread, so that no
+// other thread's call on the same context can replace them
+static thread_local archon_hip_stats t_stats[kMaxDev];
+static thread_local bool t_stats_set[kMaxDev];
 
-static int thread_slot()
+static inline int keep_stats(Ctx *c, int rc)
 {
-    static thread_local int t_slot = -1;
-    if (t_slot < 0) t_slot = (int)(g_next_slot.fetch_add(1u) % (unsigned)kCtxPerDev);
-    return t_slot;
+    t_stats[c->dev] = c->stats;
+    t_stats_set[c->dev] = true;
+    return rc;
 }
+
+static int thread_slot(int dev)
+{
+    if (!t_slot[dev]) t_slot[dev] = (signed char)(1 + g_next_slot[dev].fetch_add(1u) % (unsigned)kCtxPerDev);
+    return t_slot[dev] - 1;
+}
+
+// Product options (archon_hip_set_option), per device: read by every transform on that device when it starts.
+struct DevOpt {
+    std::atomic<uint32_t> pass_ranges{0};       // ranges the streaming passes are cut into; 0 = one per CU
+    std::atomic<uint32_t> pass_b_buckets{1};    // pass B deals whole second-byte buckets when the block is balanced
+};
+static DevOpt g_opt[kMaxDev];
 
 static int device_count()
 {
@@ -71,7 +92,7 @@ int ctx_get(int dev, Ctx **out)
         set_error("device %d out of range (have %d)", dev, ndev);
         return ARCHON_E_NODEVICE;
     }
-    const int slot = thread_slot();
+    const int slot = thread_slot(dev);
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     ARCHON_HIP_TRY(hipSetDevice(dev));
     if (!g_ctx[dev][slot]) {
@@ -111,7 +132,6 @@ int ctx_io(Ctx *c, int slot, size_t bytes, void **out)
     if (bytes > c->io_bytes[slot]) {
         ARCHON_HIP_TRY(hipDeviceSynchronize());
         if (c->io[slot]) {
-            if (slot == 1) { c->keep_bwt = nullptr; c->keep_n = 0; }
             ARCHON_HIP_TRY(hipFree(c->io[slot]));
             c->io[slot] = nullptr;
             c->io_bytes[slot] = 0;
@@ -141,8 +161,10 @@ static size_t key_words(uint32_t n)          // u64 words of a key buffer (+ 512
     return (r > (size_t)n ? r : (size_t)n) + 520;
 }
 // partial tables of the two-byte count: one per workgroup, at most 256 of them unless a test asks for more pass ranges
-static uint32_t h16_parts() { return g_route.pass_ranges > 256u ? (uint32_t)bs::kMaxRanges : 256u; }
-static size_t forward_arena_bytes(uint32_t n)
+// (a test's route wins over the device's option)
+static uint32_t eff_pass_ranges(int dev) { return g_route.pass_ranges ? g_route.pass_ranges : g_opt[dev].pass_ranges.load(); }
+static uint32_t h16_parts(int dev) { return eff_pass_ranges(dev) > 256u ? (uint32_t)bs::kMaxRanges : 256u; }
+static size_t forward_arena_bytes(uint32_t n, int dev)
 {
     const size_t N = n;
     size_t b = 0;
@@ -165,7 +187,7 @@ static size_t forward_arena_bytes(uint32_t n)
     add(sizeof(bs::Prep));
     add(sizeof(uint2) * kTieListCap);
     add(sizeof(uint4) * (size_t)bs::kMaxRanges * bs::kTrashWords);
-    add(4 * (size_t)h16_parts() * 32768u);        // partial two-byte counts, one table per workgroup of the count
+    add(4 * (size_t)h16_parts(dev) * 32768u);        // partial two-byte counts, one table per workgroup of the count
     add(4 * 1024);                            // counts, starts, ticket, err, base, totals, TieCtl
     add(8 * N + 64); add(8 * N + 64); add(8 * N + 64);      // the S lists of the refinement rounds (double-buffered) and the rank log
     add(4 * (rw::kMaxCoarse + rw::fine_buckets(n) + 64));
@@ -591,7 +613,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
 static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n, uint32_t *d_sa_user,
                        uint8_t *d_bwt, uint32_t *d_base_out)
 {
-    ARCHON_TRY(ctx_ensure_arena(c, forward_arena_bytes(n)));
+    ARCHON_TRY(ctx_ensure_arena(c, forward_arena_bytes(n, c->dev)));
     c->arena_reset();
     c->launches = 0;
     archon_hip_stats &st = c->stats;
@@ -625,7 +647,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     B.prep = c->alloc<bs::Prep>(1);                             // }  open Prep)
     B.tie_list = c->alloc<uint2>(kTieListCap);
     B.trash = c->alloc<uint4>((size_t)bs::kMaxRanges * bs::kTrashWords);
-    B.h16part = c->alloc<uint32_t>((size_t)h16_parts() * 32768u);
+    B.h16part = c->alloc<uint32_t>((size_t)h16_parts(c->dev) * 32768u);
     B.small = c->alloc<uint32_t>(1024);
     B.slist[0] = c->alloc<uint2>((size_t)n + 8);
     B.slist[1] = c->alloc<uint2>((size_t)n + 8);
@@ -664,13 +686,13 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // Pass geometry: 1024 lanes x 12 items = tiles of 12 288 items, one workgroup per CU (passes.hiph).
     constexpr uint32_t kTileItems = bs::kPassTile;
     const uint32_t ntiles = div_up(n, kTileItems);
-    // ARCHON_PASS_RANGES: ranges the passes are cut into (default: one per CU).  bench.py asks for 1024 at N > 1
+    // option "pass_ranges" (archon_hip_set_option): ranges the passes are cut into (default: one per CU).  bench.py asks for 1024 at N > 1
     // (shorter tails while RCCL's kernels hold CUs); tests use odd counts.  Whatever is asked for, a range never
     // exceeds 2^24 items (pass A stages positions relative to its range start in 24 bits).
     uint32_t R = (uint32_t)kNumCU;
-    if (g_route.pass_ranges) {
-        if (g_route.pass_ranges > (uint32_t)bs::kMaxRanges) { set_error("pass ranges %u out of range [1, %d]", g_route.pass_ranges, bs::kMaxRanges); return ARCHON_E_ARG; }
-        R = g_route.pass_ranges;
+    if (const uint32_t asked = eff_pass_ranges(c->dev)) {
+        if (asked > (uint32_t)bs::kMaxRanges) { set_error("pass ranges %u out of range [1, %d]", asked, bs::kMaxRanges); return ARCHON_E_ARG; }
+        R = asked;
     }
     if (R > ntiles) R = ntiles;
     uint32_t tpr = div_up(ntiles, R);
@@ -689,7 +711,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // device, the whole streaming stage is queued behind it, and its kernels return at once when the flag says
     // "skewed".  One host round trip per block (after k_resolve_ties) instead of two.
     // bucket-per-workgroup pass B (Prep::aligned) needs 256 workgroups and enough tiles per bucket to matter
-    const uint32_t allow_aligned = (n >= (1u << 24) && !route_off(kRtNoAligned)) ? 1u : 0u;
+    const uint32_t allow_aligned = (n >= (1u << 24) && !route_off(kRtNoAligned) && g_opt[c->dev].pass_b_buckets.load()) ? 1u : 0u;
     int e1 = -1;
     auto count16 = [&](int Q, const uint8_t *src, bool force_stream, bool probe = false, bool hot = false) -> int {
         uint32_t *d_suspect = probe ? &B.prep->suspect : nullptr;
@@ -1083,7 +1105,7 @@ int archon_hip_forward_dev(const uint8_t *d_x, uint32_t n, uint32_t *d_sa_or_nul
     std::lock_guard<std::mutex> lk(c->mu);
     ARCHON_HIP_TRY(hipSetDevice(dev));
     hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
-    return forward_run(c, s, d_x, n, d_sa_or_null, d_bwt, d_base_id);
+    return keep_stats(c, forward_run(c, s, d_x, n, d_sa_or_null, d_bwt, d_base_id));
 }
 
 int archon_hip_forward(const uint8_t *x, uint32_t n, uint32_t *sa_or_null, uint8_t *bwt, uint32_t *base_id, int dev)
@@ -1100,10 +1122,9 @@ int archon_hip_forward(const uint8_t *x, uint32_t n, uint32_t *sa_or_null, uint8
     ARCHON_TRY(ctx_io(c, 0, (size_t)n + 64, (void **)&d_x));
     ARCHON_TRY(ctx_io(c, 1, (size_t)n + 64, (void **)&d_bwt));
     if (sa_or_null) ARCHON_TRY(ctx_io(c, 2, (size_t)n * 4, (void **)&d_sa));
-    c->keep_bwt = nullptr; c->keep_n = 0;            // the staging BWT is overwritten
     uint32_t *d_base = c->d_mail + 620;
     ARCHON_HIP_TRY(hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s));
-    ARCHON_TRY(forward_run(c, s, d_x, n, d_sa, d_bwt, d_base));
+    ARCHON_TRY(keep_stats(c, forward_run(c, s, d_x, n, d_sa, d_bwt, d_base)));
     // BWT first (the block coder's enWrite can start on it), then the 4N bytes of the suffix array
     ARCHON_HIP_TRY(hipMemcpyAsync(bwt, d_bwt, n, hipMemcpyDeviceToHost, s));
     ARCHON_HIP_TRY(hipMemcpyAsync(base_id, d_base, 4, hipMemcpyDeviceToHost, s));
@@ -1112,42 +1133,209 @@ int archon_hip_forward(const uint8_t *x, uint32_t n, uint32_t *sa_or_null, uint8
     return ARCHON_OK;
 }
 
-int archon_hip_forward_keep(const uint8_t *x, uint32_t n, uint32_t *sa_or_null, uint32_t *base_id, int dev)
-{
-    if (!x || !base_id) { set_error("null pointer"); return ARCHON_E_ARG; }
-    ARCHON_TRY(check_n(n));
-    Ctx *c;
-    ARCHON_TRY(ctx_get(dev, &c));
-    std::lock_guard<std::mutex> lk(c->mu);
-    ARCHON_HIP_TRY(hipSetDevice(dev));
-    hipStream_t s = c->own_stream;
+// ---- resident blocks ---------------------------------------------------------------------------------------------------
+// What a block-coder object keeps on the device between enCompute, validate and enWrite (bwt/a7/src/main.cpp:39-46): the
+// block, its suffix array and its BWT, in buffers of its own.  The state belongs to the HANDLE -- any number of objects on
+// any number of threads; the compute arena is the calling thread's context, held only for the duration of a call.
+struct archon_hip_block {
+    int dev = 0;
+    std::mutex mu;
     uint8_t *d_x = nullptr, *d_bwt = nullptr;
     uint32_t *d_sa = nullptr;
-    ARCHON_TRY(ctx_io(c, 0, (size_t)n + 64, (void **)&d_x));
-    ARCHON_TRY(ctx_io(c, 1, (size_t)n + 64, (void **)&d_bwt));
-    if (sa_or_null) ARCHON_TRY(ctx_io(c, 2, (size_t)n * 4, (void **)&d_sa));
-    c->keep_bwt = nullptr; c->keep_n = 0;
+    size_t cap_x = 0, cap_sa = 0;
+    uint32_t n = 0, base = 0;
+    bool valid = false, has_sa = false;
+    archon_hip_stats stats;
+};
+
+static int block_reserve(archon_hip_block *b, uint32_t n, bool want_sa)
+{
+    const size_t need = (size_t)n + 64;
+    if (need > b->cap_x) {
+        if (b->d_x) (void)hipFree(b->d_x);
+        if (b->d_bwt) (void)hipFree(b->d_bwt);
+        b->d_x = b->d_bwt = nullptr;
+        b->cap_x = 0;
+        if (hipMalloc((void **)&b->d_x, need) != hipSuccess || hipMalloc((void **)&b->d_bwt, need) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("resident block: device allocation of 2 x %zu bytes failed", need);
+            return ARCHON_E_NOMEM;
+        }
+        b->cap_x = need;
+    }
+    if (want_sa && (size_t)n * 4 > b->cap_sa) {
+        if (b->d_sa) (void)hipFree(b->d_sa);
+        b->d_sa = nullptr;
+        b->cap_sa = 0;
+        if (hipMalloc((void **)&b->d_sa, (size_t)n * 4 + 64) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("resident block: device allocation of %zu bytes failed", (size_t)n * 4 + 64);
+            return ARCHON_E_NOMEM;
+        }
+        b->cap_sa = (size_t)n * 4;
+    }
+    return ARCHON_OK;
+}
+
+int archon_hip_block_create(int dev, archon_hip_block **out)
+{
+    if (!out) { set_error("null pointer"); return ARCHON_E_ARG; }
+    const int ndev = device_count();
+    if (ndev <= 0) { set_error("no HIP device available (libarchon_hip has no CPU fallback)"); return ARCHON_E_NODEVICE; }
+    if (dev < 0 || dev >= ndev || dev >= kMaxDev) { set_error("device %d out of range (have %d)", dev, ndev); return ARCHON_E_NODEVICE; }
+    archon_hip_block *b = new archon_hip_block();
+    b->dev = dev;
+    memset(&b->stats, 0, sizeof b->stats);
+    *out = b;
+    return ARCHON_OK;
+}
+
+void archon_hip_block_destroy(archon_hip_block *b)
+{
+    if (!b) return;
+    {
+        std::lock_guard<std::mutex> lk(b->mu);
+        if (b->d_x || b->d_sa) {
+            (void)hipSetDevice(b->dev);
+            if (b->d_x) (void)hipFree(b->d_x);
+            if (b->d_bwt) (void)hipFree(b->d_bwt);
+            if (b->d_sa) (void)hipFree(b->d_sa);
+        }
+    }
+    delete b;
+}
+
+int archon_hip_block_forward(archon_hip_block *b, const uint8_t *x, uint32_t n, uint32_t *sa_or_null, uint32_t *base_id)
+{
+    if (!b || !x || !base_id) { set_error("null pointer"); return ARCHON_E_ARG; }
+    ARCHON_TRY(check_n(n));
+    std::lock_guard<std::mutex> lkb(b->mu);
+    b->valid = false;
+    Ctx *c;
+    ARCHON_TRY(ctx_get(b->dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(b->dev));
+    ARCHON_TRY(block_reserve(b, n, sa_or_null != nullptr));
+    hipStream_t s = c->own_stream;
+    uint32_t *d_sa = sa_or_null ? b->d_sa : nullptr;
     uint32_t *d_base = c->d_mail + 620;
-    ARCHON_HIP_TRY(hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s));
-    ARCHON_TRY(forward_run(c, s, d_x, n, d_sa, d_bwt, d_base));
+    ARCHON_HIP_TRY(hipMemcpyAsync(b->d_x, x, n, hipMemcpyHostToDevice, s));
+    ARCHON_TRY(forward_run(c, s, b->d_x, n, d_sa, b->d_bwt, d_base));
     ARCHON_HIP_TRY(hipMemcpyAsync(base_id, d_base, 4, hipMemcpyDeviceToHost, s));
     if (sa_or_null) ARCHON_HIP_TRY(hipMemcpyAsync(sa_or_null, d_sa, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     ARCHON_HIP_TRY(hipStreamSynchronize(s));
-    c->keep_bwt = d_bwt;
-    c->keep_n = n;
+    b->n = n;
+    b->base = *base_id;
+    b->has_sa = sa_or_null != nullptr;
+    b->valid = true;
+    b->stats = c->stats;
+    t_stats[b->dev] = c->stats;
+    t_stats_set[b->dev] = true;
     return ARCHON_OK;
+}
+
+int archon_hip_block_read_bwt(archon_hip_block *b, uint32_t offset, uint32_t len, uint8_t *dst)
+{
+    if (!b || !dst) { set_error("null pointer"); return ARCHON_E_ARG; }
+    std::lock_guard<std::mutex> lkb(b->mu);
+    if (!b->valid || (uint64_t)offset + len > b->n) { set_error("no resident BWT for that range"); return ARCHON_E_ARG; }
+    ARCHON_HIP_TRY(hipSetDevice(b->dev));
+    ARCHON_HIP_TRY(hipMemcpy(dst, b->d_bwt + offset, len, hipMemcpyDeviceToHost));
+    return ARCHON_OK;
+}
+
+int archon_hip_block_validate(archon_hip_block *b)
+{
+    if (!b) { set_error("null pointer"); return ARCHON_E_ARG; }
+    std::lock_guard<std::mutex> lkb(b->mu);
+    if (!b->valid || !b->has_sa) { set_error("no resident block with its suffix array"); return ARCHON_E_ARG; }
+    Ctx *c;
+    ARCHON_TRY(ctx_get(b->dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(b->dev));
+    return validate_resident_run(c, c->own_stream, b->d_x, b->n, b->d_sa, b->d_bwt, b->base);
+}
+
+int archon_hip_block_stats(archon_hip_block *b, archon_hip_stats *out)
+{
+    if (!b || !out) { set_error("null pointer"); return ARCHON_E_ARG; }
+    std::lock_guard<std::mutex> lkb(b->mu);
+    *out = b->stats;
+    return ARCHON_OK;
+}
+
+// The (dev)-keyed form of the same: the calling thread's own default block on that device (so two threads never see each
+// other's BWT, whatever context they compute on).
+struct DefaultBlocks {
+    archon_hip_block *blk[kMaxDev] = {};
+    ~DefaultBlocks() { for (auto *b : blk) archon_hip_block_destroy(b); }
+};
+static thread_local DefaultBlocks t_blocks;
+
+static int default_block(int dev, archon_hip_block **out)
+{
+    if (dev < 0 || dev >= kMaxDev) { set_error("device %d out of range", dev); return ARCHON_E_NODEVICE; }
+    if (!t_blocks.blk[dev]) ARCHON_TRY(archon_hip_block_create(dev, &t_blocks.blk[dev]));
+    *out = t_blocks.blk[dev];
+    return ARCHON_OK;
+}
+
+int archon_hip_forward_keep(const uint8_t *x, uint32_t n, uint32_t *sa_or_null, uint32_t *base_id, int dev)
+{
+    archon_hip_block *b;
+    ARCHON_TRY(default_block(dev, &b));
+    return archon_hip_block_forward(b, x, n, sa_or_null, base_id);
 }
 
 int archon_hip_read_bwt(int dev, uint32_t offset, uint32_t len, uint8_t *dst)
 {
-    if (!dst) { set_error("null pointer"); return ARCHON_E_ARG; }
-    Ctx *c;
-    ARCHON_TRY(ctx_get(dev, &c));
-    std::lock_guard<std::mutex> lk(c->mu);
-    ARCHON_HIP_TRY(hipSetDevice(dev));
-    if (!c->keep_bwt || (uint64_t)offset + len > c->keep_n) { set_error("no resident BWT for that range"); return ARCHON_E_ARG; }
-    ARCHON_HIP_TRY(hipMemcpy(dst, c->keep_bwt + offset, len, hipMemcpyDeviceToHost));
+    archon_hip_block *b;
+    ARCHON_TRY(default_block(dev, &b));
+    return archon_hip_block_read_bwt(b, offset, len, dst);
+}
+
+int archon_hip_validate_keep(int dev)
+{
+    archon_hip_block *b;
+    ARCHON_TRY(default_block(dev, &b));
+    return archon_hip_block_validate(b);
+}
+
+int archon_hip_bind_context(int dev, int slot)
+{
+    if (dev < 0 || dev >= kMaxDev || slot < 0 || slot >= kCtxPerDev) { set_error("bind_context: device %d / context %d out of range", dev, slot); return ARCHON_E_ARG; }
+    t_slot[dev] = (signed char)(slot + 1);
     return ARCHON_OK;
+}
+
+int archon_hip_context_of_thread(int dev)
+{
+    if (dev < 0 || dev >= kMaxDev) { set_error("device %d out of range", dev); return ARCHON_E_ARG; }
+    return thread_slot(dev);
+}
+
+int archon_hip_set_option(int dev, const char *name, long value)
+{
+    if (!name) { set_error("null pointer"); return ARCHON_E_ARG; }
+    if (dev < 0 || dev >= kMaxDev) { set_error("device %d out of range", dev); return ARCHON_E_ARG; }
+    if (!strcmp(name, "pass_ranges")) {
+        if (value < 0 || value > bs::kMaxRanges) { set_error("pass_ranges=%ld out of range [0, %d]", value, bs::kMaxRanges); return ARCHON_E_ARG; }
+        g_opt[dev].pass_ranges.store((uint32_t)value);
+        return ARCHON_OK;
+    }
+    if (!strcmp(name, "pass_b_buckets")) { g_opt[dev].pass_b_buckets.store(value ? 1u : 0u); return ARCHON_OK; }
+    set_error("unknown option '%s'", name);
+    return ARCHON_E_ARG;
+}
+
+int archon_hip_get_option(int dev, const char *name, long *value)
+{
+    if (!name || !value) { set_error("null pointer"); return ARCHON_E_ARG; }
+    if (dev < 0 || dev >= kMaxDev) { set_error("device %d out of range", dev); return ARCHON_E_ARG; }
+    if (!strcmp(name, "pass_ranges")) { *value = (long)g_opt[dev].pass_ranges.load(); return ARCHON_OK; }
+    if (!strcmp(name, "pass_b_buckets")) { *value = (long)g_opt[dev].pass_b_buckets.load(); return ARCHON_OK; }
+    set_error("unknown option '%s'", name);
+    return ARCHON_E_ARG;
 }
 
 void *archon_hip_host_alloc(size_t bytes)
@@ -1173,7 +1361,7 @@ int archon_hip_inverse_dev(const uint8_t *d_bwt, uint32_t n, uint32_t base_id, u
     std::lock_guard<std::mutex> lk(c->mu);
     ARCHON_HIP_TRY(hipSetDevice(dev));
     hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
-    return inverse_run(c, s, d_bwt, n, base_id, d_x_out);
+    return keep_stats(c, inverse_run(c, s, d_bwt, n, base_id, d_x_out));
 }
 
 int archon_hip_inverse(const uint8_t *bwt, uint32_t n, uint32_t base_id, uint8_t *x_out, int dev)
@@ -1189,9 +1377,8 @@ int archon_hip_inverse(const uint8_t *bwt, uint32_t n, uint32_t base_id, uint8_t
     uint8_t *d_in = nullptr, *d_out = nullptr;
     ARCHON_TRY(ctx_io(c, 0, (size_t)n + 64, (void **)&d_in));
     ARCHON_TRY(ctx_io(c, 1, (size_t)n + 64, (void **)&d_out));
-    c->keep_bwt = nullptr; c->keep_n = 0;
     ARCHON_HIP_TRY(hipMemcpyAsync(d_in, bwt, n, hipMemcpyHostToDevice, s));
-    ARCHON_TRY(inverse_run(c, s, d_in, n, base_id, d_out));
+    ARCHON_TRY(keep_stats(c, inverse_run(c, s, d_in, n, base_id, d_out)));
     ARCHON_HIP_TRY(hipMemcpyAsync(x_out, d_out, n, hipMemcpyDeviceToHost, s));
     ARCHON_HIP_TRY(hipStreamSynchronize(s));
     return ARCHON_OK;
@@ -1242,6 +1429,18 @@ int archon_hip_validate_dev(const uint8_t *d_x, uint32_t n, const uint32_t *d_sa
     return validate_run(c, s, d_x, n, d_sa);
 }
 
+int archon_hip_validate_resident_dev(const uint8_t *d_x, uint32_t n, const uint32_t *d_sa, const uint8_t *d_bwt, uint32_t base_id, int dev, void *stream)
+{
+    if (!d_x || !d_sa || !d_bwt) { set_error("null pointer"); return ARCHON_E_ARG; }
+    ARCHON_TRY(check_n(n));
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+    return validate_resident_run(c, s, d_x, n, d_sa, d_bwt, base_id);
+}
+
 int archon_hip_validate(const uint8_t *x, uint32_t n, const uint32_t *sa, int dev)
 {
     if (!x || !sa) { set_error("null pointer"); return ARCHON_E_ARG; }
@@ -1253,7 +1452,7 @@ int archon_hip_validate(const uint8_t *x, uint32_t n, const uint32_t *sa, int de
     hipStream_t s = c->own_stream;
     uint8_t *d_x = nullptr;
     uint32_t *d_sa = nullptr;
-    ARCHON_TRY(ctx_io(c, 0, (size_t)n + 64, (void **)&d_x));      // (slot 1 may hold the BWT kept for enWrite: untouched)
+    ARCHON_TRY(ctx_io(c, 0, (size_t)n + 64, (void **)&d_x));
     ARCHON_TRY(ctx_io(c, 2, (size_t)n * 4, (void **)&d_sa));
     ARCHON_HIP_TRY(hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s));
     ARCHON_HIP_TRY(hipMemcpyAsync(d_sa, sa, (size_t)n * 4, hipMemcpyHostToDevice, s));
@@ -1305,7 +1504,6 @@ int archon_hip_sa_to_bwt(const uint8_t *x, uint32_t n, const uint32_t *sa, uint8
     ARCHON_TRY(ctx_io(c, 0, (size_t)n + 64, (void **)&d_x));
     ARCHON_TRY(ctx_io(c, 1, (size_t)n + 64, (void **)&d_bwt));
     ARCHON_TRY(ctx_io(c, 2, (size_t)n * 4 + 64, (void **)&d_sa));
-    c->keep_bwt = nullptr; c->keep_n = 0;
     ARCHON_HIP_TRY(hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s));
     ARCHON_HIP_TRY(hipMemcpyAsync(d_sa, sa, (size_t)n * 4, hipMemcpyHostToDevice, s));
     ARCHON_TRY(sa_to_bwt_run(c, s, d_x, n, d_sa, d_bwt, c->d_mail + 610));
@@ -1363,7 +1561,8 @@ int archon_hip_forward_post(const uint8_t *x, uint32_t n, uint8_t *out, size_t c
 {
     if (!x || !out || !out_bytes || !base_id) { set_error("null pointer"); return ARCHON_E_ARG; }
     ARCHON_TRY(check_n(n));
-    if (cap < post::block_bound(n)) { set_error("post stage: output buffer of %zu bytes, %zu needed (archon_hip_post_bound)", cap, post::block_bound(n)); return ARCHON_E_ARG; }
+    // (cap may be smaller than archon_hip_post_bound(n), the format's worst case of 20 bits per symbol: the stream is built on the
+    //  device at full size and a stream longer than cap is an error of this call -- nothing is truncated)
     Ctx *c;
     ARCHON_TRY(ctx_get(dev, &c));
     std::lock_guard<std::mutex> lk(c->mu);
@@ -1373,11 +1572,11 @@ int archon_hip_forward_post(const uint8_t *x, uint32_t n, uint8_t *out, size_t c
     ARCHON_TRY(ctx_io(c, 0, (size_t)n + 64, (void **)&d_x));
     ARCHON_TRY(ctx_io(c, 1, (size_t)n + 64, (void **)&d_bwt));
     ARCHON_TRY(ctx_io(c, 2, post::block_bound(n) + 64, (void **)&d_pk));
-    c->keep_bwt = nullptr; c->keep_n = 0;
     uint32_t *d_base = c->d_mail + 620;
     ARCHON_HIP_TRY(hipMemcpyAsync(d_x, x, n, hipMemcpyHostToDevice, s));
-    ARCHON_TRY(forward_run(c, s, d_x, n, nullptr, d_bwt, d_base));
+    ARCHON_TRY(keep_stats(c, forward_run(c, s, d_x, n, nullptr, d_bwt, d_base)));
     ARCHON_TRY(post_run(c, s, d_bwt, n, d_pk, out_bytes));
+    if (*out_bytes > cap) { set_error("post stage: stream of %zu bytes, output buffer of %zu (archon_hip_post_bound gives the worst case)", *out_bytes, cap); return ARCHON_E_ARG; }
     // only the packed stream crosses the link
     ARCHON_HIP_TRY(hipMemcpyAsync(out, d_pk, *out_bytes, hipMemcpyDeviceToHost, s));
     ARCHON_HIP_TRY(hipMemcpyAsync(base_id, d_base, 4, hipMemcpyDeviceToHost, s));
@@ -1387,7 +1586,7 @@ int archon_hip_forward_post(const uint8_t *x, uint32_t n, uint8_t *out, size_t c
 
 static int lms_select_run(Ctx *c, hipStream_t s, const uint8_t *d_x, uint32_t n, uint32_t *d_count, uint32_t *d_items, uint32_t *n1_out)
 {
-    ARCHON_TRY(ctx_ensure_arena(c, forward_arena_bytes(n)));
+    ARCHON_TRY(ctx_ensure_arena(c, forward_arena_bytes(n, c->dev)));
     c->arena_reset();
     c->launches = 0;
     uint32_t *v = c->alloc<uint32_t>(n), *flag = c->alloc<uint32_t>(n), *dst = c->alloc<uint32_t>(n);
@@ -1511,7 +1710,7 @@ int archon_hip_reserve(uint32_t n, int dev, size_t *bytes_or_null)
     ARCHON_TRY(ctx_get(dev, &c));
     std::lock_guard<std::mutex> lk(c->mu);
     ARCHON_HIP_TRY(hipSetDevice(dev));
-    size_t need = forward_arena_bytes(n);
+    size_t need = forward_arena_bytes(n, dev);
     const size_t inv = inverse_arena_bytes(n);
     if (inv > need) need = inv;
     ARCHON_TRY(ctx_ensure_arena(c, need));
@@ -1606,11 +1805,8 @@ int archon_hip_test_route(const char *name, long value)
 int archon_hip_get_stats(int dev, archon_hip_stats *out)
 {
     if (!out) { set_error("null pointer"); return ARCHON_E_ARG; }
-    const int slot = thread_slot();                  // the calling thread's own context: the statistics of ITS last call
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
-    if (dev < 0 || dev >= kMaxDev || !g_ctx[dev][slot]) { set_error("no context on device %d", dev); return ARCHON_E_ARG; }
-    std::lock_guard<std::mutex> lk2(g_ctx[dev][slot]->mu);
-    *out = g_ctx[dev][slot]->stats;
+    if (dev < 0 || dev >= kMaxDev || !t_stats_set[dev]) { set_error("the calling thread has run no transform on device %d", dev); return ARCHON_E_ARG; }
+    *out = t_stats[dev];
     return ARCHON_OK;
 }
 

@@ -27,7 +27,8 @@
 #include "../../include/archon_hip.h"
 
 static const unsigned short kSig = 0x5241;       // 'RA' as x3 writes it
-static const unsigned short kSigPost = 0x4D52;   // 'RM': blocks carry the MTF + entropy stage (archon_post.cpp, parity unpinned)
+static const unsigned short kSigPost = 0x4E52;   // 'RN': blocks carry the MTF + entropy stage (archon_post.cpp, parity unpinned); the header names the piece size
+static const unsigned short kSigPostV1 = 0x4D52; // 'RM': the first revision of that format (pieces of 4 MiB, size not in the header) -- recognised, refused
 
 extern "C" {
 size_t archon_post_bound(size_t n);
@@ -65,6 +66,7 @@ struct Pipe {
             s.out = static_cast<byte *>(archon_hip_host_alloc(out_bytes));
             s.pinned = s.in && s.out;
             if (!s.pinned) {
+                fprintf(stderr, "archon: %zu + %zu bytes of pinned host memory not available: slot in pageable memory (copies will not overlap)\n", bytes, out_bytes);
                 if (s.in) archon_hip_host_free(s.in);
                 if (s.out) archon_hip_host_free(s.out);
                 s.in = static_cast<byte *>(malloc(bytes));
@@ -131,10 +133,14 @@ void worker_loop(Pipe &p, int first, int step, int dev, Work work)
 // (archon_hip_forward_post: one workgroup per piece, only the packed stream comes back over the link); decoding is a pool
 // of host threads.
 // Packed block: u32 pieces | u32 packed bytes of each piece | the pieces.
-constexpr size_t kPiece = 32u << 10;
+constexpr size_t kPieceEnc = 32u << 10;       // what the encoder (csrc/post.hiph) cuts; the decoder takes the size from the file header
+// Host slot of a packed block: an order-0 code over the MTF ranks of n bytes stays under 9/8 n + tables; the worst case the
+// format allows (archon_hip_post_bound: 20 bits per symbol) would pin 2.5 n per slot -- 30 GB on an 8-GPU node at 256 MiB
+// blocks -- for streams that cannot occur.  A stream that does not fit is an error of the call, not a silent truncation.
+static size_t post_slot_bytes(size_t n) { return n + n / 4 + (n / kPieceEnc + 2) * 1100 + 4096; }
 
 // returns the block length n, or -1 on a malformed stream; bwt must hold `cap` bytes
-long post_unpack(const byte *in, size_t in_bytes, byte *bwt, size_t cap)
+long post_unpack(const byte *in, size_t in_bytes, byte *bwt, size_t cap, size_t kPiece)
 {
     if (in_bytes < 4) return -1;
     uint32_t np;
@@ -175,8 +181,10 @@ int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev, int po
 {
     if (ndev < 1) return -4;
     if (fwrite(post ? &kSigPost : &kSig, 2, 1, fo) != 1 || fwrite(&bsize, 4, 1, fo) != 1) return -3;     // (a full disk shows here first)
+    const uint32_t piece = (uint32_t)kPieceEnc;
+    if (post && fwrite(&piece, 4, 1, fo) != 1) return -3;
     Pipe p;
-    const size_t out_cap = post ? archon_hip_post_bound(bsize) + 4 : (size_t)bsize + 4;
+    const size_t out_cap = post ? post_slot_bytes(bsize) : (size_t)bsize + 4;
     if (!p.alloc((kWorkersPerGpu + 2) * ndev, (size_t)bsize + 4, out_cap)) return ARCHON_E_NOMEM;
 
     std::thread reader([&] {
@@ -193,6 +201,7 @@ int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev, int po
     std::vector<std::thread> workers;
     for (int w = 0; w < kWorkersPerGpu * ndev; ++w)
         workers.emplace_back([&, w] {
+            archon_hip_bind_context(w % ndev, w / ndev);        // the two workers of a GPU on its two contexts, whatever order they start in
             worker_loop(p, w, kWorkersPerGpu * ndev, w % ndev, [post, out_cap](Slot &s, int dev) {
                 if (post) return archon_hip_forward_post(s.in, (uint32_t)s.n, s.out, out_cap, &s.packed, &s.base, dev);
                 return archon_hip_forward(s.in, (uint32_t)s.n, NULL, s.out, &s.base, dev);
@@ -224,9 +233,14 @@ int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out)
     if (ndev < 1) return -4;
     unsigned short sig = 0;
     uint32_t bsize = 0;
-    if (fread(&sig, 2, 1, fi) != 1 || (sig != kSig && sig != kSigPost)) return -3;
+    if (fread(&sig, 2, 1, fi) != 1) return -3;
+    if (sig == kSigPostV1) { fprintf(stderr, "archon: 'RM' container of the first post-stage revision (4 MiB pieces): not readable by this build\n"); return -3; }
+    if (sig != kSig && sig != kSigPost) return -3;
     const bool post = sig == kSigPost;
     if (fread(&bsize, 4, 1, fi) != 1 || bsize < 8 || bsize > (1u << 28)) return -3;
+    uint32_t piece = 0;
+    if (post && (fread(&piece, 4, 1, fi) != 1 || piece < 1024 || piece > (4u << 20))) return -3;
+    const size_t kPiece = piece;
     if (bsize_out) *bsize_out = bsize;
     Pipe p;
     if (!p.alloc((kWorkersPerGpu + 2) * ndev, (size_t)bsize + 4)) return ARCHON_E_NOMEM;
@@ -240,7 +254,7 @@ int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out)
                 if (fread(&sz, 4, 1, fi) != 1 || sz > 4 + ((size_t)bsize / kPiece + 1) * (4 + archon_post_bound(kPiece))) { p.fail(-2); return; }
                 std::vector<byte> packed(sz);
                 if (fread(packed.data(), 1, sz, fi) != sz || fread(&s->base, 4, 1, fi) != 1) { p.fail(-2); return; }
-                const long n = post_unpack(packed.data(), sz, s->in, bsize);
+                const long n = post_unpack(packed.data(), sz, s->in, bsize, kPiece);
                 if (n < 0) { p.fail(-2); return; }
                 s->n = (size_t)n;
             } else {
@@ -259,6 +273,7 @@ int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out)
     std::vector<std::thread> workers;
     for (int w = 0; w < kWorkersPerGpu * ndev; ++w)
         workers.emplace_back([&, w] {
+            archon_hip_bind_context(w % ndev, w / ndev);
             worker_loop(p, w, kWorkersPerGpu * ndev, w % ndev, [](Slot &s, int dev) {
                 return archon_hip_inverse(s.in, (uint32_t)s.n, s.base, s.out, dev);
             });

@@ -32,7 +32,7 @@ static void *block_alloc(size_t bytes, bool *pinned)
 }
 
 Archon::Archon(const t_index Nx)
-    : Nmax(Nx), Nreserve(estimateReserve(Nx)), P(NULL), str(NULL), N(0), baseId(0), dev(0), pinned(false), last_rc(0)
+    : Nmax(Nx), Nreserve(estimateReserve(Nx)), P(NULL), str(NULL), N(0), baseId(0), dev(0), pinned(false), last_rc(0), blk(NULL)
 {
     bool p1 = false, p2 = false;
     *const_cast<suffix **>(&P) = static_cast<suffix *>(block_alloc(((size_t)Nmax + Nreserve) * sizeof(suffix), &p1));
@@ -49,8 +49,15 @@ Archon::Archon(const t_index Nx)
 
 Archon::~Archon()
 {
+    archon_hip_block_destroy(blk);
     if (pinned) { archon_hip_host_free(P); archon_hip_host_free(str); }
     else { free(P); free(str); }
+}
+
+void Archon::setDevice(int d)
+{
+    if (d != dev && blk) { archon_hip_block_destroy(blk); blk = NULL; }      // what is resident lives on the old device
+    dev = d;
 }
 
 unsigned Archon::countMemory() const
@@ -61,7 +68,11 @@ unsigned Archon::countMemory() const
 // --- ENCODING (archon.cpp:862-900) -------------------------------------------------
 bool Archon::validate()
 {
-    last_rc = archon_hip_validate(str, N, P, dev);
+    // The reference walks P and str on the host (archon.cpp:862-874).  Here enCompute has left the block, its suffix array
+    // and its BWT on the device: the check runs on what is there -- no 5N-byte upload, no second gather of str[P[i]].
+    // (An object that has not computed anything has nothing resident: the host arrays are checked instead.)
+    last_rc = blk ? archon_hip_block_validate(blk) : ARCHON_E_ARG;
+    if (last_rc == ARCHON_E_ARG) last_rc = archon_hip_validate(str, N, P, dev);
     return last_rc == 1;
 }
 
@@ -74,8 +85,12 @@ int Archon::enRead(FILE *const fx, t_index ns)
 
 int Archon::enCompute()
 {
-    // P[0..N) <- suffix array; the BWT stays in HBM until enWrite fetches it
-    last_rc = archon_hip_forward_keep(str, N, P, &baseId, dev);
+    // P[0..N) <- suffix array; block, suffix array and BWT stay in HBM, in this object's own handle, for validate / enWrite
+    if (!blk) {
+        last_rc = archon_hip_block_create(dev, &blk);
+        if (last_rc != ARCHON_OK) return last_rc;
+    }
+    last_rc = archon_hip_block_forward(blk, str, N, P, &baseId);
     return last_rc;
 }
 
@@ -88,7 +103,7 @@ int Archon::enWrite(FILE *const fx)
     const t_index cap = Nreserve * (t_index)sizeof(suffix);
     for (t_index off = 0; off < N;) {
         const t_index len = N - off < cap ? N - off : cap;
-        last_rc = archon_hip_read_bwt(dev, off, len, bounce);
+        last_rc = blk ? archon_hip_block_read_bwt(blk, off, len, bounce) : ARCHON_E_ARG;
         if (last_rc != ARCHON_OK) return last_rc;
         if (fwrite(bounce, 1, len, fx) != len) return -1;
         off += len;
@@ -138,4 +153,5 @@ const uint32_t *archon_sa(const archon_t *a) { return a->impl.sa(); }
 uint32_t archon_base_id(const archon_t *a) { return a->impl.baseIndex(); }
 uint32_t archon_length(const archon_t *a) { return a->impl.length(); }
 void archon_set_device(archon_t *a, int dev) { a->impl.setDevice(dev); }
+int archon_last_error(const archon_t *a) { return a->impl.lastError(); }
 }

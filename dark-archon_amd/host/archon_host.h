@@ -18,6 +18,7 @@ class Archon {
     int dev;
     bool pinned;
     int last_rc;
+    struct archon_hip_block *blk;   // the object's resident block on the device (x, SA, BWT between enCompute, validate and enWrite)
 
 public:
     static t_index estimateReserve(const t_index);
@@ -37,6 +38,6 @@ public:
     const suffix *sa() const { return P; }
     t_index baseIndex() const { return baseId; }
     t_index length() const { return N; }
-    void setDevice(int d) { dev = d; }
+    void setDevice(int d);
     int lastError() const { return last_rc; }
 };

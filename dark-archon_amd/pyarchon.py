@@ -26,6 +26,10 @@ SYMBOLS = [
     "archon_hip_validate_dev", "archon_hip_radix_scatter_dev", "archon_hip_sa_to_bwt", "archon_hip_sa_to_bwt_dev",
     "archon_hip_lms_select", "archon_hip_lms_select_dev",
     "archon_hip_reserve", "archon_hip_release", "archon_hip_get_stats",
+    "archon_hip_block_create", "archon_hip_block_destroy", "archon_hip_block_forward", "archon_hip_block_read_bwt",
+    "archon_hip_block_validate", "archon_hip_block_stats", "archon_hip_validate_keep",
+    "archon_hip_bind_context", "archon_hip_context_of_thread", "archon_hip_set_option", "archon_hip_get_option",
+    "archon_hip_post_bound", "archon_hip_post_encode_dev", "archon_hip_forward_post", "archon_hip_validate_resident_dev",
 ]
 
 
@@ -83,16 +87,31 @@ def load():
         "archon_hip_inverse_dev": [vp, u32, u32, vp, i32, vp],
         "archon_hip_hist256_dev": [vp, sz, vp, i32, vp],
         "archon_hip_validate_dev": [vp, u32, vp, i32, vp],
+        "archon_hip_validate_resident_dev": [vp, u32, vp, vp, u32, i32, vp],
         "archon_hip_radix_scatter_dev": [vp, sz, vp, i32, vp],
         "archon_hip_reserve": [u32, i32, vp],
         "archon_hip_release": [i32],
         "archon_hip_get_stats": [i32, ctypes.POINTER(Stats)],
+        "archon_hip_block_create": [i32, vp],
+        "archon_hip_block_forward": [vp, vp, u32, vp, vp],
+        "archon_hip_block_read_bwt": [vp, u32, u32, vp],
+        "archon_hip_block_validate": [vp],
+        "archon_hip_block_stats": [vp, ctypes.POINTER(Stats)],
+        "archon_hip_forward_keep": [vp, u32, vp, vp, i32],
+        "archon_hip_read_bwt": [i32, u32, u32, vp],
+        "archon_hip_validate_keep": [i32],
+        "archon_hip_bind_context": [i32, i32],
+        "archon_hip_context_of_thread": [i32],
+        "archon_hip_set_option": [i32, ctypes.c_char_p, ctypes.c_long],
+        "archon_hip_get_option": [i32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_long)],
         "archon_hip_post_encode_dev": [vp, u32, vp, sz, vp, i32, vp],
         "archon_hip_forward_post": [vp, u32, vp, sz, vp, vp, i32],
     }.items():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = i32
+    lib.archon_hip_block_destroy.argtypes = [vp]
+    lib.archon_hip_block_destroy.restype = None
     lib.archon_hip_post_bound.argtypes = [u32]
     lib.archon_hip_post_bound.restype = sz
     lib.archon_hip_test_route.argtypes = [ctypes.c_char_p, ctypes.c_long]      # include/archon_hip_test.h (tests only)
@@ -113,8 +132,8 @@ _ROUTE_NAMES = ("FORCE_PATH", "PASS_RANGES", "INV_SLAB", "INV_SBITS", "INV_WALK_
 def _sync_routes(L):
     global _routes_seen
     now = tuple(os.environ.get("ARCHON_" + k) for k in _ROUTE_NAMES)
-    if now == _routes_seen:
-        return
+    if now == _routes_seen or (_routes_seen is None and not any(v is not None for v in now)):
+        return          # (a process that names no route never touches the test hook)
     _routes_seen = now
     L.archon_hip_test_route(b"RESET", 0)
     for k, v in zip(_ROUTE_NAMES, now):
@@ -228,6 +247,68 @@ def reserve(n, dev=0):
     return b.value
 
 
+def set_option(name, value, dev=0):
+    """product option of a device (include/archon_hip.h: "pass_ranges", "pass_b_buckets")"""
+    _check(lib().archon_hip_set_option(dev, name.encode(), int(value)))
+
+
+def get_option(name, dev=0):
+    v = ctypes.c_long(0)
+    _check(lib().archon_hip_get_option(dev, name.encode(), ctypes.byref(v)))
+    return int(v.value)
+
+
+def bind_context(slot, dev=0):
+    _check(lib().archon_hip_bind_context(dev, slot))
+
+
+def context_of_thread(dev=0):
+    return _check(lib().archon_hip_context_of_thread(dev))
+
+
+class Block:
+    """archon_hip_block: the device side of one block-coder object (x, SA and BWT resident between compute, validate, write)"""
+
+    def __init__(self, dev=0):
+        h = ctypes.c_void_p(None)
+        _check(lib().archon_hip_block_create(dev, ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib().archon_hip_block_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, x, want_sa=True):
+        x = np.ascontiguousarray(x, dtype=np.uint8)
+        self.n = x.size
+        sa = np.empty(x.size, dtype=np.uint32) if want_sa else None
+        base = ctypes.c_uint32(0)
+        _check(lib().archon_hip_block_forward(self.h, _p(x), x.size, _p(sa) if want_sa else None,
+                                              ctypes.cast(ctypes.byref(base), ctypes.c_void_p)))
+        return sa, base.value
+
+    def read_bwt(self, offset=0, length=None):
+        length = self.n - offset if length is None else length
+        out = np.empty(length, dtype=np.uint8)
+        _check(lib().archon_hip_block_read_bwt(self.h, offset, length, _p(out)))
+        return out
+
+    def validate(self):
+        return bool(_check(lib().archon_hip_block_validate(self.h)))
+
+    def stats(self):
+        s = Stats()
+        _check(lib().archon_hip_block_stats(self.h, ctypes.byref(s)))
+        return s.asdict()
+
+
 # ---------------------------------------------------------------- device resident (torch)
 def _stream_ptr():
     import torch
@@ -259,3 +340,10 @@ def validate_dev(x_t, sa_t):
     dev = x_t.device.index or 0
     return bool(_check(lib().archon_hip_validate_dev(ctypes.c_void_p(x_t.data_ptr()), x_t.numel(),
                                                      ctypes.c_void_p(sa_t.data_ptr()), dev, _stream_ptr())))
+
+
+def validate_resident_dev(x_t, sa_t, bwt_t, base_id):
+    """Archon::validate on the outputs of a forward pass that are still on the device (no second gather of x[sa[i]])"""
+    dev = x_t.device.index or 0
+    return bool(_check(lib().archon_hip_validate_resident_dev(ctypes.c_void_p(x_t.data_ptr()), x_t.numel(), ctypes.c_void_p(sa_t.data_ptr()),
+                                                              ctypes.c_void_p(bwt_t.data_ptr()), int(base_id), dev, _stream_ptr())))

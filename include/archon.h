@@ -39,7 +39,8 @@ int       archon_de_write(archon_t *a, FILE *fx);               /* deWrite,   ar
 const uint32_t *archon_sa(const archon_t *a);          /* P[0..N) after en_compute */
 uint32_t  archon_base_id(const archon_t *a);
 uint32_t  archon_length(const archon_t *a);
-void      archon_set_device(archon_t *a, int dev);     /* default 0 (or $ARCHON_DEVICE) */
+void      archon_set_device(archon_t *a, int dev);     /* default 0 (or $ARCHON_DEVICE); before the first en_compute */
+int       archon_last_error(const archon_t *a);        /* the library's code of the object's last compute / validate call */
 
 /* ---- optional post-BWT stage of the container CLI (`archon e -m -b<size>`): move-to-front, zero runs and an
  * order-0 canonical Huffman code over one piece of BWT output.  PARITY UNPINNED: the reference

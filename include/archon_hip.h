@@ -21,11 +21,15 @@
  *
  * Error model: 0 = ok, negative = ARCHON_E_* below (the reference returns int
  * from every Archon method, archon.h:16-28).  The library owns device memory and
- * streams: two contexts per device (arena, staging buffers, stream each), created
- * lazily; a host thread is bound to one of them at its first call, so one thread sees
- * strictly serial behaviour and two threads feeding one GPU overlap one block's copies
- * with the other's kernels; separate devices run concurrently.  Callers own every
- * buffer they pass.  There is NO CPU fallback: without a HIP
+ * streams: two compute contexts per device (arena, staging buffers, stream each),
+ * created lazily.  A host thread is bound to one context PER DEVICE: the k-th thread
+ * that comes to device d takes context k mod 2 of that device, or the one it names
+ * with archon_hip_bind_context.  One thread sees strictly serial behaviour; two
+ * threads feeding one GPU overlap one block's copies with the other's kernels;
+ * separate devices run concurrently.  A context holds NO results between calls:
+ * what outlives a call (the resident block of a block-coder object) belongs to an
+ * archon_hip_block handle, and the statistics of a call to the thread that made it.
+ * Callers own every buffer they pass.  There is NO CPU fallback: without a HIP
  * device every compute entry point returns ARCHON_E_NODEVICE.
  *
  * Limits: 1 <= n <= ARCHON_HIP_MAX_N (the reference needs n < 2^30 for its
@@ -63,13 +67,33 @@ const char *archon_hip_last_error(void);
 int archon_hip_forward(const uint8_t *x, uint32_t n, uint32_t *sa_or_null,
                        uint8_t *bwt, uint32_t *base_id, int dev);
 
-/* Block-coder form used by the host object (include/archon.h), which must stay
- * within the reference's 5N + O(1) host bytes: the suffix array goes to sa[n], the
- * BWT stays resident in HBM and is read back in pieces through any O(1) bounce
- * buffer with archon_hip_read_bwt (valid until the next call on `dev`). */
+/* ---- resident blocks: the device side of ONE block-coder object (class Archon, bwt/a7/src/archon.h:8-29) ----------
+ * The reference's caller runs read -> enCompute -> validate -> enWrite on one object (main.cpp:39-46), and the host
+ * must stay within 5N + O(1) bytes.  So enCompute leaves the block, its suffix array and its BWT resident in HBM, in
+ * buffers that belong to the handle (6N device bytes): validate then checks what is there (no upload, no second
+ * gather of x[sa[i]]), enWrite reads the BWT back in pieces through any O(1) bounce buffer.  Any number of handles,
+ * on any threads; a handle is used by one thread at a time (as an Archon object is: a7 is re-entrant per object). */
+typedef struct archon_hip_block archon_hip_block;
+int  archon_hip_block_create(int dev, archon_hip_block **out);
+void archon_hip_block_destroy(archon_hip_block *b);
+/* Archon::enCompute (archon.cpp:882-885): x[n] (host) -> sa[n] (host, optional) and *base_id; x, SA, BWT stay resident */
+int  archon_hip_block_forward(archon_hip_block *b, const uint8_t *x, uint32_t n, uint32_t *sa_or_null, uint32_t *base_id);
+/* the gather loop of Archon::enWrite (archon.cpp:887-900), already done on the device: bytes [offset, offset+len) of the BWT */
+int  archon_hip_block_read_bwt(archon_hip_block *b, uint32_t offset, uint32_t len, uint8_t *dst);
+/* Archon::validate (archon.cpp:862-874) on the resident block: every sa[i] in 1..n, exactly one n and on the primary
+ * row, the LF rule for every other row, the BWT a permutation of the block.  1 = consistent, 0 = not, <0 = error
+ * (ARCHON_E_ARG when the last forward on the handle kept no suffix array). */
+int  archon_hip_block_validate(archon_hip_block *b);
+/* (archon_hip_stats is defined under "measurement" below) */
+struct archon_hip_stats;
+int  archon_hip_block_stats(archon_hip_block *b, struct archon_hip_stats *out);      /* of the handle's last forward */
+
+/* The same keyed by device, on a default handle that belongs to the CALLING THREAD (so two threads never see each
+ * other's BWT): forward_keep = block_forward, read_bwt = block_read_bwt, validate_keep = block_validate. */
 int archon_hip_forward_keep(const uint8_t *x, uint32_t n, uint32_t *sa_or_null,
                             uint32_t *base_id, int dev);
 int archon_hip_read_bwt(int dev, uint32_t offset, uint32_t len, uint8_t *dst);
+int archon_hip_validate_keep(int dev);
 
 /* pinned host memory for block buffers (faster PCIe copies); plain malloc works too */
 void *archon_hip_host_alloc(size_t bytes);
@@ -112,6 +136,11 @@ int archon_hip_inverse_dev(const uint8_t *d_bwt, uint32_t n, uint32_t base_id,
                            uint8_t *d_x_out, int dev, void *stream);
 int archon_hip_hist256_dev(const uint8_t *d_x, size_t n, uint32_t *d_out256, int dev, void *stream);
 int archon_hip_validate_dev(const uint8_t *d_x, uint32_t n, const uint32_t *d_sa, int dev, void *stream);
+/* Archon::validate for a caller that holds the forward pass's outputs on the device: like archon_hip_validate_dev, but the
+ * rows' symbols are taken from d_bwt (checked to be a permutation of the block) instead of being gathered again, and
+ * base_id must be the row that holds n.  This is what archon_hip_block_validate runs.  1 / 0 / <0. */
+int archon_hip_validate_resident_dev(const uint8_t *d_x, uint32_t n, const uint32_t *d_sa, const uint8_t *d_bwt, uint32_t base_id,
+                                     int dev, void *stream);
 int archon_hip_sa_to_bwt_dev(const uint8_t *d_x, uint32_t n, const uint32_t *d_sa, uint8_t *d_bwt, uint32_t *d_base_id,
                              int dev, void *stream);
 int archon_hip_radix_scatter_dev(const uint8_t *d_src, size_t n, uint8_t *d_dst, int dev, void *stream);
@@ -120,9 +149,27 @@ int archon_hip_lms_select_dev(const uint8_t *d_x, uint32_t n, uint32_t *d_count2
 
 /* ---- workspace / lifetime ---------------------------------------------------- */
 
-/* Pre-size the arena of the calling thread's context for blocks up to n bytes (optional;
- * the arena grows on demand).  Returns bytes reserved via *bytes_or_null. */
+/* Pre-size the arena of the calling thread's context on `dev` for blocks up to n bytes (optional; the arena grows on
+ * demand; the thread that reserves should be the one that transforms, or have bound itself to the same context).
+ * Returns bytes reserved via *bytes_or_null. */
 int archon_hip_reserve(uint32_t n, int dev, size_t *bytes_or_null);
+
+/* Bind the calling thread to compute context `slot` (0 or 1) of `dev` -- what a pool of workers does so that the two
+ * workers of one GPU never share a context whatever order they start in (host/archon_container.cpp: worker w of G GPUs
+ * drives GPU w mod G on context w / G).  Without it the k-th thread to reach a device gets context k mod 2 of that
+ * device.  archon_hip_context_of_thread returns the binding (and makes the default one if there is none yet). */
+int archon_hip_bind_context(int dev, int slot);
+int archon_hip_context_of_thread(int dev);
+
+/* Product options, per device; read by every transform on that device when it starts.
+ *   "pass_ranges"     ranges the two streaming LSB passes are cut into: 0 = one per CU (default), 1..1024.  More, shorter
+ *                     ranges shorten the tail when other kernels hold CUs beside the sort (RCCL's copy kernels while a
+ *                     gather overlaps the next block: bench.py asks for 1024 at N > 1).
+ *   "pass_b_buckets"  1 (default): LSB pass B deals whole second-byte buckets, one per workgroup, when the block is
+ *                     balanced; 0: always by ranges (every workgroup the same work: again for a chip that is shared).
+ * Every setting yields the same output. */
+int archon_hip_set_option(int dev, const char *name, long value);
+int archon_hip_get_option(int dev, const char *name, long *value);
 
 /* Free the device's contexts (arenas, staging buffers, streams, events). */
 int archon_hip_release(int dev);
@@ -135,13 +182,14 @@ int archon_hip_release(int dev);
 size_t archon_hip_post_bound(uint32_t n);      /* bytes the stream of an n-byte block can take at most */
 /* BWT on the device -> its stream on the device; *out_bytes = the stream's length (returned after a stream sync) */
 int archon_hip_post_encode_dev(const uint8_t *d_bwt, uint32_t n, uint8_t *d_out, size_t cap, size_t *out_bytes, int dev, void *stream);
-/* host block -> forward BWT -> stream, host buffers: only the packed stream and the primary index come back over the link */
+/* host block -> forward BWT -> stream, host buffers: only the packed stream and the primary index come back over the link.
+ * cap may be below archon_hip_post_bound(n): a stream longer than cap makes the call fail with ARCHON_E_ARG (nothing is cut). */
 int archon_hip_forward_post(const uint8_t *x, uint32_t n, uint8_t *out, size_t cap, size_t *out_bytes, uint32_t *base_id, int dev);
 
 /* ---- measurement ------------------------------------------------------------- */
 
 /* Per-stage device times (HIP events on the stream the kernels ran on) and
- * work counters of the most recent forward/inverse call on `dev`. */
+ * work counters of the CALLING THREAD's most recent forward/inverse call on `dev`. */
 typedef struct archon_hip_stats {
     uint32_t n;                  /* block size of the call */
     uint32_t radix_passes;       /* LSB radix passes executed by the first-stage sort */

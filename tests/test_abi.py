@@ -150,3 +150,55 @@ def test_reference_main_builds_against_the_shim(tmp_path):
     inp.write_bytes(b"abracadabra" * 10)
     r = subprocess.run([exe, "e", str(inp), str(tmp_path / "out.bwt")], capture_output=True, text=True)
     assert "Encoding SA..." in r.stdout
+
+
+def test_options_and_context_binding_need_no_gpu():
+    """archon_hip_set_option / archon_hip_bind_context (include/archon_hip.h): host-side state, per device.
+    ADVICE r3: the context binding is per (thread, device) -- the two workers of one GPU must land on its two contexts on
+    a node with an even number of GPUs, whatever order the threads start in."""
+    import threading
+    import pyarchon
+    L = pyarchon.lib()
+    assert pyarchon.get_option("pass_ranges", 3) == 0 and pyarchon.get_option("pass_b_buckets", 3) == 1
+    pyarchon.set_option("pass_ranges", 1024, 3)
+    assert pyarchon.get_option("pass_ranges", 3) == 1024 and pyarchon.get_option("pass_ranges", 2) == 0       # per device
+    pyarchon.set_option("pass_ranges", 0, 3)
+    with pytest.raises(pyarchon.ArchonError):
+        pyarchon.set_option("pass_ranges", 5000, 3)
+    with pytest.raises(pyarchon.ArchonError):
+        pyarchon.set_option("no_such_option", 1, 3)
+    # eight threads, two "GPUs" (devices 40 and 41: no HIP call is made), started in block order as the container's workers are:
+    # worker w drives device 40 + w % 2.  Each device must see both of its contexts in use.
+    ndev, seen = 2, {}
+    order = threading.Semaphore(1)
+
+    def worker(w):
+        with order:
+            seen[w] = L.archon_hip_context_of_thread(40 + w % ndev)
+    ts = [threading.Thread(target=worker, args=(w,)) for w in range(4)]
+    for t in ts:
+        t.start()
+        t.join()                       # strictly in worker order: the case that broke the process-wide counter
+    for d in range(ndev):
+        assert sorted(seen[w] for w in range(4) if w % ndev == d) == [0, 1], seen
+    # an explicit binding wins and is per device
+    res = {}
+
+    def bound():
+        L.archon_hip_bind_context(42, 1)
+        res["a"] = (L.archon_hip_context_of_thread(42), L.archon_hip_context_of_thread(43))
+    t = threading.Thread(target=bound)
+    t.start()
+    t.join()
+    assert res["a"][0] == 1 and res["a"][1] == 0
+    assert L.archon_hip_bind_context(42, 2) < 0 and L.archon_hip_bind_context(-1, 0) < 0
+
+
+def test_bench_uses_the_product_api_only():
+    """what bench.py sets for N > 1 (pass ranges, pass B by ranges) goes through archon_hip_set_option -- the
+    bench names neither the test header's call nor a route variable."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "archon_hip_test_route" not in src and "ARCHON_PASS_RANGES" not in src and "ARCHON_NO_" not in src
+    assert 'set_option("pass_ranges"' in src
+    shard = open(os.path.join(ROOT, "dark-archon_amd", "archon_shard.py")).read()
+    assert "test_route" not in shard and "ARCHON_" not in shard

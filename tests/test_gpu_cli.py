@@ -180,6 +180,100 @@ def test_concurrent_host_threads(archon, oracle):
         assert (sa == P).all() and (bwt == B).all() and base == b0, i
 
 
+def _block_coder_lib():
+    _build()
+    L = ctypes.CDLL(os.path.join(ROOT, "dark-archon_amd", "libarchon.so"))
+    L.archon_create.restype = ctypes.c_void_p
+    L.archon_create.argtypes = [ctypes.c_uint32]
+    L.archon_sa.restype = ctypes.POINTER(ctypes.c_uint32)
+    for fn in ("archon_destroy", "archon_validate", "archon_en_compute", "archon_sa", "archon_base_id", "archon_length"):
+        getattr(L, fn).argtypes = [ctypes.c_void_p]
+    L.archon_en_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    L.archon_en_write.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    libc = ctypes.CDLL(None)
+    libc.fopen.restype = ctypes.c_void_p
+    libc.fopen.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    libc.fclose.argtypes = [ctypes.c_void_p]
+    return L, libc
+
+
+def test_block_coder_objects_keep_their_own_blocks(archon, oracle, tmp_path):
+    """the resident block (x, SA, BWT) belongs to the Archon OBJECT.  Six objects on six threads, blocks of
+    EQUAL size, every thread runs en_compute -> (barrier: all have computed) -> validate -> en_write: with the state keyed
+    by context (two per device) four of the six used to write another object's BWT -- silently, the sizes agree."""
+    import threading
+    L, libc = _block_coder_lib()
+    n, T = 150001, 6
+    blocks = [S.gen_shape(sh, n, block=i) for i, sh in enumerate(["random", "text", "dna", "random", "text", "dna"])]
+    want = [oracle.forward(x) for x in blocks]
+    for i, x in enumerate(blocks):
+        x.tofile(tmp_path / ("x%d.raw" % i))
+    barrier = threading.Barrier(T)
+    errs = []
+
+    def work(i):
+        try:
+            a = L.archon_create(n)
+            fx = libc.fopen(str(tmp_path / ("x%d.raw" % i)).encode(), b"rb")
+            assert L.archon_en_read(a, fx, n) == n
+            libc.fclose(fx)
+            for rep in range(2):
+                assert L.archon_en_compute(a) == 0
+                barrier.wait(60)                      # every object has computed before any of them validates or writes
+                assert L.archon_validate(a) == 1
+                fo = libc.fopen(str(tmp_path / ("y%d.bwt" % i)).encode(), b"wb")
+                assert L.archon_en_write(a, fo) == 0
+                libc.fclose(fo)
+                barrier.wait(60)
+            P = np.ctypeslib.as_array(L.archon_sa(a), shape=(n,)).copy()
+            assert (P == want[i][0]).all()
+            L.archon_destroy(a)
+        except Exception as e:      # noqa: BLE001
+            errs.append((i, repr(e)))
+            barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(180)
+    assert not errs, errs
+    for i, (P, B, b0) in enumerate(want):
+        f = np.fromfile(tmp_path / ("y%d.bwt" % i), np.uint8)
+        assert (f[:-4] == B).all() and int(f[-4:].view("<u4")[0]) == b0, i
+
+
+def test_resident_block_handles(archon, oracle):
+    """archon_hip_block_*: forward keeps x / SA / BWT on the device; validate runs on what is there (and rejects a handle
+    that kept no suffix array); read_bwt in pieces; the (dev)-keyed forms use a default handle of the calling thread."""
+    x = S.gen_text(70001)
+    P, B, b0 = oracle.forward(x)
+    blk = archon.Block()
+    sa, base = blk.forward(x)
+    assert (sa == P).all() and base == b0
+    assert blk.validate() is True
+    got = np.concatenate([blk.read_bwt(0, 1000), blk.read_bwt(1000, 69001)])
+    assert (got == B).all()
+    assert blk.stats()["n"] == x.size
+    other = archon.Block()
+    y = S.gen_dna(70001)
+    other.forward(y)
+    assert (blk.read_bwt() == B).all()                       # another handle's forward does not disturb this one
+    _, base2 = blk.forward(x, want_sa=False)
+    assert base2 == b0 and (blk.read_bwt() == B).all()
+    with pytest.raises(archon.ArchonError):
+        blk.validate()                                       # no resident suffix array
+    with pytest.raises(archon.ArchonError):
+        blk.read_bwt(70000, 2)
+    blk.close(); other.close()
+    L = archon.lib()
+    base = ctypes.c_uint32(0)
+    sa2 = np.empty(x.size, np.uint32)
+    assert L.archon_hip_forward_keep(ctypes.c_void_p(x.ctypes.data), x.size, ctypes.c_void_p(sa2.ctypes.data),
+                                     ctypes.cast(ctypes.byref(base), ctypes.c_void_p), 0) == 0
+    assert L.archon_hip_validate_keep(0) == 1 and (sa2 == P).all()
+
+
 def test_config5_mixed_corpus_full_size(archon, tmp_path):
     """BASELINE.json configs[4] at full size: a 1 GiB mixed corpus (4 x 256 MiB: text, random, DNA, 1000-byte motif)
     -- every block forward + inverse through the C ABI with its BWT||baseId checked against the reference's digest

@@ -12,9 +12,8 @@ x_t = torch.from_numpy(S.gen_random(n)).cuda()
 sa_t = torch.empty(n, dtype=torch.int32, device="cuda"); bwt_t = torch.empty(n, dtype=torch.uint8, device="cuda")
 base_t = torch.zeros(1, dtype=torch.int32, device="cuda")
 for ranges, aligned in (("256", None), ("1024", "1")):
-    os.environ["ARCHON_PASS_RANGES"] = ranges
-    if aligned: os.environ["ARCHON_NO_ALIGNED"] = aligned
-    else: os.environ.pop("ARCHON_NO_ALIGNED", None)
+    pyarchon.set_option("pass_ranges", int(ranges))          # the product options bench.py sets at N > 1
+    pyarchon.set_option("pass_b_buckets", 0 if aligned else 1)
     for k in (0, 1, 2, 8, 32):
         best = 1e9
         for rep in range(3):
