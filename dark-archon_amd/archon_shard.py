@@ -45,9 +45,14 @@ class GatherPipe:
     """The path's one exchange step as bench.py runs it: per step every rank contributes one fixed-size payload
     (BWT || baseId of its block) to ONE gather on rank `dst`; the gather is asynchronous and double-buffered, so the
     gather of step k (RCCL's own stream) overlaps the sort of step k+1.  `via_host` stages through host memory
-    (gloo rehearsal on fewer GPUs than ranks)."""
+    (gloo rehearsal on fewer GPUs than ranks).
 
-    def __init__(self, dist, rank, world, payload_bytes, device, via_host=False, dst=0, rotate=False):
+    The collective is ISSUED from a helper thread: `submit()` only hands the step over, so the host time of the call into
+    torch.distributed (0.1-0.3 ms of Python and C++ per gather) runs beside the next block's kernels instead of in
+    front of them -- the forward call that follows releases the GIL for its whole duration.  One helper thread per
+    pipe issues the gathers strictly in step order, on every rank alike."""
+
+    def __init__(self, dist, rank, world, payload_bytes, device, via_host=False, dst=0, rotate=False, threaded=True):
         """rotate: the gather of step k lands on rank (dst + k) mod world instead of always on `dst` -- every rank takes its
         turn as the root, so no GPU has to take in world - 1 payloads per step (7 x 256 MiB next to its own sort): the
         outputs of step k (blocks k * world .. k * world + world - 1, one contiguous stretch of the container) then sit
@@ -58,33 +63,82 @@ class GatherPipe:
         self.lists = [None, None]
         if dist is not None and (rotate or rank == dst):
             self.lists = [[torch.empty(payload_bytes, dtype=torch.uint8, device=gdev) for _ in range(world)] for _ in range(2)]
-        self.pending = [None, None]
+        self.pending = [None, None]          # per buffer: the work handle, once the helper has issued the gather
+        self.issued = [None, None]           # per buffer: threading.Event set when the helper has issued it (or failed)
+        self.error = None
         self.step_no = 0
+        self.device = device
+        self.queue = None
+        if dist is not None and threaded:
+            import queue
+            import threading
+            self.queue = queue.Queue()
+            self.thread = threading.Thread(target=self._issuer, daemon=True)
+            self.thread.start()
 
     def root_of(self, step):
         return (self.dst + step) % self.world if self.rotate else self.dst
 
-    def next_buffer(self):
-        """payload buffer of the coming step (waits until its previous gather has completed)"""
-        k = self.step_no & 1
+    def _issue(self, k, step):
+        src = self.outs[k].cpu() if self.via_host else self.outs[k]
+        root = self.root_of(step)
+        self.pending[k] = self.dist.gather(src, self.lists[k] if self.rank == root else None, dst=root, async_op=True)
+
+    def _issuer(self):
+        if self.device is not None and getattr(self.device, "type", "cpu") == "cuda":
+            torch.cuda.set_device(self.device)
+        while True:
+            job = self.queue.get()
+            if job is None:
+                return
+            k, step, ev = job
+            try:
+                self._issue(k, step)
+            except Exception as e:      # noqa: BLE001  (reported by the next wait on this buffer)
+                self.error = e
+            ev.set()
+
+    def _wait(self, k):
+        if self.issued[k] is not None:
+            self.issued[k].wait()
+            self.issued[k] = None
+        if self.error is not None:
+            raise self.error
         if self.pending[k] is not None:
             self.pending[k].wait()
             self.pending[k] = None
+
+    def next_buffer(self):
+        """payload buffer of the coming step (waits until its previous gather has completed)"""
+        k = self.step_no & 1
+        self._wait(k)
         return self.outs[k]
 
     def submit(self):
+        """the payload of the current step is complete in its buffer (the producer has synchronised): gather it"""
         k = self.step_no & 1
+        step = self.step_no
         self.step_no += 1
-        if self.dist is not None:
-            src = self.outs[k].cpu() if self.via_host else self.outs[k]
-            root = self.root_of(self.step_no - 1)
-            self.pending[k] = self.dist.gather(src, self.lists[k] if self.rank == root else None, dst=root, async_op=True)
+        if self.dist is None:
+            return
+        if self.queue is None:
+            self._issue(k, step)
+            return
+        import threading
+        ev = threading.Event()
+        self.issued[k] = ev
+        self.queue.put((k, step, ev))
 
     def drain(self):
         for k in range(2):
-            if self.pending[k] is not None:
-                self.pending[k].wait()
-                self.pending[k] = None
+            self._wait(k)
+
+    def close(self):
+        self.drain()
+        if self.queue is not None:
+            self.queue.put(None)
+            self.thread.join(10)
+            self.queue = None
 
     def last(self):
         """(own payload buffer, gathered list -- valid on last_root() only) of the most recent step"""

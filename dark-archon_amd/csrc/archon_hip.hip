@@ -7,6 +7,7 @@
 #include "forward.hiph"
 #include "rounds.hiph"
 #include "rank_writer.hiph"
+#include "mid_rounds.hiph"
 #include "inverse.hiph"
 #include "post.hiph"
 
@@ -164,6 +165,9 @@ static size_t key_words(uint32_t n)          // u64 words of a key buffer (+ 512
 // (a test's route wins over the device's option)
 static uint32_t eff_pass_ranges(int dev) { return g_route.pass_ranges ? g_route.pass_ranges : g_opt[dev].pass_ranges.load(); }
 static uint32_t h16_parts(int dev) { return eff_pass_ranges(dev) > 256u ? (uint32_t)bs::kMaxRanges : 256u; }
+// groups the B list / a mid directory can hold: a group of the B list is longer than the S list's limit or straddles a
+// tile of the sweep that made it (at most one per tile)
+static size_t mid_dir_cap(uint32_t n) { return (size_t)n / 512 + 64; }
 static size_t forward_arena_bytes(uint32_t n, int dev)
 {
     const size_t N = n;
@@ -191,6 +195,9 @@ static size_t forward_arena_bytes(uint32_t n, int dev)
     add(4 * 1024);                            // counts, starts, ticket, err, base, totals, TieCtl
     add(8 * N + 64); add(8 * N + 64); add(8 * N + 64);      // the S lists of the refinement rounds (double-buffered) and the rank log
     add(4 * (rw::kMaxCoarse + rw::fine_buckets(n) + 64));
+    add(4 * 4 * (mid_dir_cap(n) + 8));                          // directory of the B list: first entry, first row, place in the big list, number among the big groups
+    for (int i = 0; i < 4; ++i) add(16 * (mid_dir_cap(n) + 8)); // directories of the two mid classes, double-buffered
+    add(4 * fwd::kMcWords);
     return b + 4096;
 }
 
@@ -208,6 +215,9 @@ struct FwdBuf {
     uint32_t *h16part;         // packed partial two-byte counts, one 128 KiB table per workgroup of k_hist16
     uint4 *trash;              // write-only trash lines of the pass workgroups (passes.hiph, emit_rec)
     rs::Scratch sc;
+    // mid_rounds.hiph: directory of the B list, the class directories of the mid lists (double-buffered), the counters
+    uint32_t *gdir_off, *gdir_row, *gcls, *gbig, *mc;
+    uint4 *dirS[2], *dirL[2];
 };
 
 // A5 + A7 for whatever the first stage left tied.  On entry (k_first_groups): sa[] holds the items in first-stage order,
@@ -325,6 +335,14 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     uint32_t *vT = B.valA, *vS = B.valB;
     uint32_t h = h0;
     uint32_t ms = 0, mb = 0, bgroups = 1;
+    // the mid lists (mid_rounds.hiph): entries / groups of the two classes in the CURRENT list (buffer `cur`)
+    uint32_t mm = 0, mdS = 0, mdL = 0;
+    {
+        uint32_t init[fwd::kMcWords] = {};
+        init[fwd::kMcTop] = init[fwd::kMcTop + 1] = n;
+        memcpy(c->h_mail + 4200, init, sizeof init);
+        ARCHON_HIP_TRY(hipMemcpyAsync(B.mc, c->h_mail + 4200, sizeof init, hipMemcpyHostToDevice, s));
+    }
     int cs = 0;
     unsigned long long *fg_status = reinterpret_cast<unsigned long long *>(B.sc.d_status);
     if (m && lists_ready) {
@@ -379,33 +397,94 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         const uint32_t ms_kept = b_only ? ms : 0u;
         if (b_only) ms = 0;
         const uint32_t chain = (chain_next && chain_ok && mode == 0 && ms) ? 1u : 0u;
-        // many rank updates: dealt by item into windows of the table (rank_writer.hiph) instead of one random store each
-        const bool writer = mode != 1 && writer_ok && (uint64_t)ms + mb >= (8u << 20);
-        const uint32_t m_before = ms + mb;
+        const uint32_t m_before = ms + mb + mm;
         ARCHON_HIP_TRY(hipMemsetAsync(d_fu, 0, 6 * sizeof(uint32_t), s));
         if (ms_kept) ARCHON_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_fu, (int)ms_kept, 1, s));      // k_b_finish appends behind the kept entries
         uint2 *s_next = b_only ? B.slist[cs] : B.slist[cs ^ 1];
+        // Mid groups (mid_rounds.hiph): the B list is dealt out by group length -- groups of at most 16 Ki entries are sorted by
+        // ONE workgroup each, in LDS (with the groups the mid kernels made last round); only the longer ones take the global
+        // sort below.  (Text rounds keep round 3's path: they run on small sets.)
+        const bool mid = mode != 1 && !route_off(kRtNoMid);
+        uint32_t nS = mdS, nL = mdL, nbig = mb, nbig_groups = bgroups, mid_from_b = 0;
+        const int nxt = cur ^ 1;
+        if (mid) {
+            // the next list starts empty: no groups, its items from the top of the buffer downwards
+            c->h_mail[4200] = 0; c->h_mail[4201] = n;
+            ARCHON_HIP_TRY(hipMemcpyAsync(B.mc + fwd::kMcSmall + nxt, c->h_mail + 4200, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            ARCHON_HIP_TRY(hipMemcpyAsync(B.mc + fwd::kMcLarge + nxt, c->h_mail + 4200, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            ARCHON_HIP_TRY(hipMemcpyAsync(B.mc + fwd::kMcTop + nxt, c->h_mail + 4201, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            if (mb) {
+                const uint32_t tiles = div_up(mb, fwd::kBfTile);
+                ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
+                ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
+                hipLaunchKernelGGL(fwd::k_b_dir, dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], mb, B.gdir_off, B.gdir_row, fg_status, B.sc.d_ticket, B.sc.d_err, B.mc, (uint32_t)mid_dir_cap(n));
+                hipLaunchKernelGGL(fwd::k_b_plan, dim3(1), dim3(1024), 0, s, B.gdir_off, B.gdir_row, mb, B.gcls, B.gbig, B.dirS[cur], B.dirL[cur], B.mc, (uint32_t)cur,
+                                   (uint32_t)fwd::kMidSmallCap, (uint32_t)fwd::kMidLargeCap, (uint32_t)mid_dir_cap(n), B.sc.d_err);
+                ARCHON_HIP_TRY(hipGetLastError());
+                ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 4200, B.mc, fwd::kMcWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                ARCHON_HIP_TRY(hipStreamSynchronize(s));
+                c->launches += 2;
+                if (c->h_mail[4200 + fwd::kMcGroups] > mid_dir_cap(n)) { set_error("B list of %u entries holds %u groups (directory: %zu)", mb, c->h_mail[4200], mid_dir_cap(n)); return ARCHON_E_INTERNAL; }
+                nS = c->h_mail[4200 + fwd::kMcSmall + cur];
+                nL = c->h_mail[4200 + fwd::kMcLarge + cur];
+                nbig = c->h_mail[4200 + fwd::kMcBigEntries];
+                nbig_groups = c->h_mail[4200 + fwd::kMcBigGroups];
+                mid_from_b = c->h_mail[4200 + fwd::kMcMidEntries];
+                if (nbig + mid_from_b != mb) { set_error("plan of the B list lost entries (%u + %u of %u)", nbig, mid_from_b, mb); return ARCHON_E_INTERNAL; }
+            }
+        }
+        const uint32_t mid_entries = mid ? mm + mid_from_b : 0u;
+        st.mid_items += mid_entries;
+        // many rank updates: dealt by item into windows of the table (rank_writer.hiph) instead of one random store each
+        const bool writer = mode != 1 && writer_ok && (uint64_t)ms + mb + mm >= (8u << 20);
         // B: keys (the gather) now, global sort on (group, key) behind the S kernel -- which so runs while the host waits for
         // the sort's digit counts
         uint32_t shift = 32, gbits = 1;
         if (mode != 1) { shift = 1; while ((2ull * n + (mode == 2 ? 2u : 0u)) >> shift) ++shift; }    // bits of a key k < 2n (mode 2: 2n + 2)
-        while ((uint64_t)bgroups >> gbits) ++gbits;                                 // bits of a group number of the B list
+        while ((uint64_t)nbig_groups >> gbits) ++gbits;                             // bits of a group number of the (big) B list
         const uint32_t nbytes = (shift + gbits + 7) / 8;
-        const uint32_t mb_round = mb;
-        if (mb) {
-            st.seg_big_items += mb;
+        const uint32_t mb_round = nbig;
+        const bool split = mid && mb != 0;
+        if (nbig) {
+            st.seg_big_items += nbig;
             const uint32_t tiles = div_up(mb, fwd::kBfTile);
             ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
             ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
             ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ghist, 0, 8 * 256 * sizeof(uint32_t), s));
 #define ARCHON_B_KEYS(M) hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_keys<M>), dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], B.uitem[cur], B.rank, d_x, hh, n, \
                                             shift, mb, kT, vT, fg_status, B.sc.d_ticket, B.sc.d_err, B.sc.d_ghist, nbytes, B.brk, cert, okey)
-            if (mode == 0) ARCHON_B_KEYS(0);
+#define ARCHON_B_KEYS_SPLIT(M) hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_keys_split<M>), dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], B.uitem[cur], B.rank, d_x, hh, n, \
+                                            shift, mb, kT, vT, fg_status, B.sc.d_ticket, B.sc.d_err, B.sc.d_ghist, nbytes, B.brk, cert, okey, \
+                                            B.gdir_off, B.gcls, B.gbig, B.upos[nxt], B.ug[nxt])
+            if (split) {
+                if (mode == 0) ARCHON_B_KEYS_SPLIT(0);
+                else if (mode == 2) ARCHON_B_KEYS_SPLIT(2);
+                else ARCHON_B_KEYS_SPLIT(3);
+            } else if (mode == 0) ARCHON_B_KEYS(0);
             else if (mode == 1) ARCHON_B_KEYS(1);
             else if (mode == 2) ARCHON_B_KEYS(2);
             else ARCHON_B_KEYS(3);
 #undef ARCHON_B_KEYS
+#undef ARCHON_B_KEYS_SPLIT
             ++c->launches;
+        }
+        if (mid && (nS || nL)) {
+#define ARCHON_MID(M, LN, DIRP, CNT) hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_mid_round<M, LN>), dim3(CNT), dim3(LN), 0, s, DIRP, B.uitem[cur], B.rank, d_x, hh, n, sa, s_next, \
+                                                        B.rlog, d_fu, B.uitem[nxt], B.dirS[nxt], B.dirL[nxt], (uint32_t)mid_dir_cap(n), B.mc, (uint32_t)nxt, d_bwt, d_base, B.brk, cert, okey, B.sc.d_err)
+            if (nL) {
+                if (mode == 0) ARCHON_MID(0, fwd::kMidLargeLanes, B.dirL[cur], nL);
+                else if (mode == 2) ARCHON_MID(2, fwd::kMidLargeLanes, B.dirL[cur], nL);
+                else ARCHON_MID(3, fwd::kMidLargeLanes, B.dirL[cur], nL);
+                ++c->launches;
+            }
+            if (nS) {
+                if (mode == 0) ARCHON_MID(0, fwd::kMidSmallLanes, B.dirS[cur], nS);
+                else if (mode == 2) ARCHON_MID(2, fwd::kMidSmallLanes, B.dirS[cur], nS);
+                else ARCHON_MID(3, fwd::kMidSmallLanes, B.dirS[cur], nS);
+                ++c->launches;
+            }
+#undef ARCHON_MID
+            ARCHON_HIP_TRY(hipGetLastError());
         }
         if (ms) {
             const dim3 grid(div_up(ms, fwd::kFuT)), block(fwd::kFuLanes);
@@ -420,43 +499,56 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             ++c->launches;
         }
         uint2 *b_log = nullptr;
-        if (mb) {
+        if (nbig) {
             uint32_t passes = 0;
             bool b_in_b = false;
-            ARCHON_TRY(rs::sort_pairs(s, B.sc, kT, vT, kS, vS, mb, (1u << nbytes) - 1u, &b_in_b, &passes, &c->launches, nullptr, nullptr, nullptr, true));
-            const uint32_t tiles = div_up(mb, fwd::kBfTile);
+            ARCHON_TRY(rs::sort_pairs(s, B.sc, kT, vT, kS, vS, nbig, (1u << nbytes) - 1u, &b_in_b, &passes, &c->launches, nullptr, nullptr, nullptr, true));
+            const uint32_t tiles = div_up(nbig, fwd::kBfTile);
             ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
             ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
             const uint64_t *ks = b_in_b ? kS : kT;
             const uint32_t *vs = b_in_b ? vS : vT;
             b_log = writer ? reinterpret_cast<uint2 *>(b_in_b ? kT : kS) : nullptr;        // the sort's other key buffer is free now
+            // (split: the big groups' rows and old group starts lie compacted in the NEXT list's buffers, which k_b_finish then
+            //  overwrites in place -- a tile writes at or below its own positions, and only once every tile before it has
+            //  published its totals, which it does after loading its entries)
+            const int src = split ? nxt : cur;
             if (mode != 1)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_finish<0>), dim3(tiles), dim3(256), 0, s, ks, vs, B.upos[cur], B.ug[cur], mb, sa, B.rank, s_next, d_fu,
-                                   B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1], fg_status, B.sc.d_ticket, B.sc.d_err, d_x, d_bwt, d_base, n, b_log);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_finish<0>), dim3(tiles), dim3(256), 0, s, ks, vs, B.upos[src], B.ug[src], nbig, sa, B.rank, s_next, d_fu,
+                                   B.upos[nxt], B.ug[nxt], B.uitem[nxt], fg_status, B.sc.d_ticket, B.sc.d_err, d_x, d_bwt, d_base, n, b_log);
             else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_finish<1>), dim3(tiles), dim3(256), 0, s, ks, vs, B.upos[cur], B.ug[cur], mb, sa, B.v, s_next, d_fu,
-                                   B.upos[cur ^ 1], B.ug[cur ^ 1], B.uitem[cur ^ 1], fg_status, B.sc.d_ticket, B.sc.d_err, d_x, d_bwt, d_base, n, b_log);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_finish<1>), dim3(tiles), dim3(256), 0, s, ks, vs, B.upos[src], B.ug[src], nbig, sa, B.v, s_next, d_fu,
+                                   B.upos[nxt], B.ug[nxt], B.uitem[nxt], fg_status, B.sc.d_ticket, B.sc.d_err, d_x, d_bwt, d_base, n, b_log);
             ARCHON_HIP_TRY(hipGetLastError());
             ++c->launches;
-            cur ^= 1;                           // (short groups that straddle a tile of that sweep stay in B for another round)
         }
-        if (writer) {                           // the round's rank updates (S: the log; B: k_b_finish's), now that every key has been read
+        const bool flip = mid || mb != 0;           // (short groups that straddle a tile of k_b_finish's sweep stay in B for another round)
+        const uint32_t slog_cap = ms + mid_entries;         // what the S log can hold this round: the S kernel's and the mid kernels' updates
+        if (writer) {                           // the round's rank updates (S and mid: the log; B: k_b_finish's), now that every key has been read
             B.rwb.r1 = reinterpret_cast<uint2 *>(b_log == reinterpret_cast<uint2 *>(kT) ? kS : kT);       // the key buffer that is not the B log
             B.rwb.r2 = reinterpret_cast<uint2 *>(B.valA);
             ARCHON_HIP_TRY(hipMemsetAsync(B.rwb.cnt1, 0, (rw::kMaxCoarse + rw::fine_buckets(n)) * sizeof(uint32_t), s));
-            if (ms) hipLaunchKernelGGL(HIP_KERNEL_NAME(rw::k_part<1, 0>), dim3(div_up(ms, rw::kTile)), dim3(rw::kLanes), 0, s, B.rlog, d_fu + 1, 0u, nullptr, nullptr, nullptr, B.rwb.r1, B.rwb.cnt1);
+            if (slog_cap) hipLaunchKernelGGL(HIP_KERNEL_NAME(rw::k_part<1, 0>), dim3(div_up(slog_cap, rw::kTile)), dim3(rw::kLanes), 0, s, B.rlog, d_fu + 1, 0u, nullptr, nullptr, nullptr, B.rwb.r1, B.rwb.cnt1);
             if (b_log) hipLaunchKernelGGL(HIP_KERNEL_NAME(rw::k_part<1, 0>), dim3(div_up(mb_round, rw::kTile)), dim3(rw::kLanes), 0, s, b_log, nullptr, mb_round, nullptr, nullptr, nullptr, B.rwb.r1, B.rwb.cnt1);
             ARCHON_TRY(rw::write_back(s, B.rwb, n, B.rank, &c->launches));
             c->launches += 2;
-        } else if (mode != 1 && ms) {           // the S list's rank updates, now that every key of the round has been read
-            hipLaunchKernelGGL(fwd::k_rank_apply, dim3(div_up(ms, 256)), dim3(256), 0, s, B.rlog, d_fu + 1, B.rank);
+        } else if (mode != 1 && slog_cap) {     // the S list's and the mid lists' rank updates, now that every key of the round has been read
+            hipLaunchKernelGGL(fwd::k_rank_apply, dim3(div_up(slog_cap, 256)), dim3(256), 0, s, B.rlog, d_fu + 1, B.rank);
             ++c->launches;
         }
+        if (mid) ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 4200, B.mc, fwd::kMcWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_fu, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         ms = c->h_mail[0];
         mb = mb_round ? c->h_mail[2] : 0u;
         bgroups = c->h_mail[3];
+        if (mid) {
+            mdS = c->h_mail[4200 + fwd::kMcSmall + nxt];
+            mdL = c->h_mail[4200 + fwd::kMcLarge + nxt];
+            mm = n - c->h_mail[4200 + fwd::kMcTop + nxt];
+            if (mdS > mid_dir_cap(n) || mdL > mid_dir_cap(n)) { set_error("mid directory overflow (%u / %u groups)", mdS, mdL); return ARCHON_E_INTERNAL; }
+        }
+        if (flip) cur ^= 1;
         if (!b_only) cs ^= 1;
         uint32_t np = chain ? c->h_mail[4] : 0u;
         const uint32_t pairs_seen = chain ? np : c->h_mail[5];
@@ -482,7 +574,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         }
         // the next round lists its pairs when this one got nowhere and pairs are most of what is left
         if (chain_cool) --chain_cool;
-        const uint32_t m_after = ms + mb;
+        const uint32_t m_after = ms + mb + mm;
         chain_next = chain_ok && !chain_cool && (uint64_t)m_after * 4 >= (uint64_t)m_before * 3 && (uint64_t)pairs_seen * 4 >= ms && ms;
         return ARCHON_OK;
     };
@@ -496,7 +588,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         ARCHON_TRY(do_round(1, h));
         trace("text round");
         h += 4;
-        const uint32_t m2 = ms + mb;
+        const uint32_t m2 = ms + mb + mm;
         const bool productive = (uint64_t)m2 * 2 <= m;
         m = m2;
         if (!productive) break;
@@ -521,7 +613,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     // certify the groups whose members share a whole period (k_zone_certify) and run the break rounds on those alone --
     // unless the defects are so many that the byte-by-byte comparisons of the certification would cost more than the rounds.
     if (m && mb && z_period && h < z_period && (uint64_t)z_breaks * z_period * z_period <= 8ull * n && !route_off(kRtNoBreakRound)) {
-        uint8_t *cert = reinterpret_cast<uint8_t *>(B.rlog);                 // (the S list sits these rounds out: its rank log is idle)
+        uint8_t *cert = reinterpret_cast<uint8_t *>(B.pairw);                // (2n bytes, idle until a doubling round lists pairs; the rank log takes the mid kernels' updates)
         uint32_t *okey = B.keep;                                             // (idle until a doubling round lists pairs)
         ARCHON_HIP_TRY(hipMemsetAsync(cert, 0, n, s));
         ARCHON_HIP_TRY(hipMemsetAsync(okey, 0, (size_t)n * sizeof(uint32_t), s));
@@ -530,15 +622,15 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         ++c->launches;
         trace("zone certify");
         for (bool distance = true;; distance = false) {
-            st.unresolved_total += mb;
+            st.unresolved_total += mb + mm;
             ++st.break_rounds;
-            const uint32_t before = ms + mb;
+            const uint32_t before = ms + mb + mm;
             ARCHON_TRY(do_round(distance ? 2 : 3, z_period, true, cert, okey));
-            const uint32_t settled = before - (ms + mb);
+            const uint32_t settled = before - (ms + mb + mm);
             st.break_settled += settled;
-            m = ms + mb;
+            m = ms + mb + mm;
             trace(distance ? "break round on certified groups (distance)" : "break round on certified groups (continuation)");
-            if (!mb || (!distance && !settled)) break;
+            if (!(mb + mm) || (!distance && !settled)) break;
         }
     }
     while (m) {
@@ -565,9 +657,9 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
                             std::chrono::duration<double, std::milli>(t1 - t0).count(), ms, mb);
                 }
 #endif
-                const uint32_t settled = m - (ms + mb);
+                const uint32_t settled = m - (ms + mb + mm);
                 st.break_settled += settled;
-                m = ms + mb;
+                m = ms + mb + mm;
                 z_first = false;
                 if (!m) break;
                 if (!distance) {
@@ -582,13 +674,13 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
 #ifdef ARCHON_EXPERIMENTS
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         const auto t0 = std::chrono::steady_clock::now();
-        const uint32_t ms0 = ms, mb0 = mb;
+        const uint32_t ms0 = ms, mb0 = mb, mm0 = mm;
 #endif
         ARCHON_TRY(do_round(0, h));
 #ifdef ARCHON_EXPERIMENTS
         if (getenv("ARCHON_TRACE_ROUNDS")) {
             const auto t1 = std::chrono::steady_clock::now();
-            fprintf(stderr, "round h=%u S=%u B=%u %.3f ms -> S=%u B=%u\n", h, ms0, mb0, std::chrono::duration<double, std::milli>(t1 - t0).count(), ms, mb);
+            fprintf(stderr, "round h=%u S=%u B=%u M=%u %.3f ms -> S=%u B=%u M=%u (%u + %u groups)\n", h, ms0, mb0, mm0, std::chrono::duration<double, std::milli>(t1 - t0).count(), ms, mb, mm, mdS, mdL);
             if (ms0 && getenv("ARCHON_TRACE_STAMPS")) {
                 unsigned long long v[24];
                 if (hipMemcpyFromSymbol(v, HIP_SYMBOL(fwd::g_fu_stamps), sizeof v) == hipSuccess) {
@@ -599,7 +691,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             }
         }
 #endif
-        m = ms + mb;
+        m = ms + mb + mm;
         if (h > n && m) {   // h >= n resolves everything; reaching here means an internal fault
             set_error("doubling did not converge (m=%u at h=%u)", m, h);
             return ARCHON_E_INTERNAL;
@@ -656,7 +748,16 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     B.rwb.r1 = B.rwb.r2 = nullptr;
     B.rwb.cnt1 = c->alloc<uint32_t>(rw::kMaxCoarse + rw::fine_buckets(n) + 64);
     B.rwb.cnt2 = B.rwb.cnt1 ? B.rwb.cnt1 + rw::kMaxCoarse : nullptr;
-    if (!B.small || !B.rlog || !B.rwb.cnt1) {
+    B.gdir_off = c->alloc<uint32_t>(mid_dir_cap(n) + 8);
+    B.gdir_row = c->alloc<uint32_t>(mid_dir_cap(n) + 8);
+    B.gcls = c->alloc<uint32_t>(mid_dir_cap(n) + 8);
+    B.gbig = c->alloc<uint32_t>(mid_dir_cap(n) + 8);
+    for (int i = 0; i < 2; ++i) {
+        B.dirS[i] = c->alloc<uint4>(mid_dir_cap(n) + 8);
+        B.dirL[i] = c->alloc<uint4>(mid_dir_cap(n) + 8);
+    }
+    B.mc = c->alloc<uint32_t>(fwd::kMcWords);
+    if (!B.small || !B.rlog || !B.rwb.cnt1 || !B.mc) {
         set_error("arena exhausted");
         return ARCHON_E_NOMEM;
     }
@@ -1781,7 +1882,7 @@ int archon_hip_test_route(const char *name, long value)
         {"NO_ALIGNED", kRtNoAligned}, {"NO_CHAINS", kRtNoChains}, {"NO_DEEP_HINT", kRtNoDeepHint}, {"NO_PACK", kRtNoPack},
         {"NO_PACK_STREAM", kRtNoPackStream}, {"NO_PAIR_CHAINS", kRtNoPairChains}, {"NO_PERIOD_HINT", kRtNoPeriodHint},
         {"NO_BREAK_ROUND", kRtNoBreakRound}, {"NO_PERIOD_PROBE", kRtNoPeriodProbe}, {"NO_PERIOD_STREAM", kRtNoPeriodStream}, {"NO_PROBE", kRtNoProbe},
-        {"NO_RANK_WRITER", kRtNoRankWriter}, {"NO_TEXT_ROUNDS", kRtNoTextRounds},
+        {"NO_RANK_WRITER", kRtNoRankWriter}, {"NO_TEXT_ROUNDS", kRtNoTextRounds}, {"NO_MID", kRtNoMid},
     };
     if (!strcmp(name, "RESET")) { g_route = Route(); return ARCHON_OK; }
     if (!strcmp(name, "FORCE_PATH")) { g_route.force_path = value < 0 ? -1 : (value ? 1 : 0); return ARCHON_OK; }

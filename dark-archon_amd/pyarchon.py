@@ -48,6 +48,7 @@ class Stats(ctypes.Structure):
         ("alphabet_bits", ctypes.c_uint32), ("period", ctypes.c_uint32),
         ("chain_items", ctypes.c_uint32), ("text_rounds", ctypes.c_uint32), ("seg_big_items", ctypes.c_uint64),
         ("chain_pairs", ctypes.c_uint64), ("break_rounds", ctypes.c_uint32), ("break_settled", ctypes.c_uint32),
+        ("mid_items", ctypes.c_uint64),
     ]
 
     def asdict(self):
@@ -126,7 +127,7 @@ _routes_seen = None
 # before the next call into the library.
 _ROUTE_NAMES = ("FORCE_PATH", "PASS_RANGES", "INV_SLAB", "INV_SBITS", "INV_WALK_WGS", "NO_ALIGNED", "NO_CHAINS", "NO_DEEP_HINT",
                 "NO_PACK", "NO_PACK_STREAM", "NO_PAIR_CHAINS", "NO_PERIOD_HINT", "NO_BREAK_ROUND", "NO_PERIOD_PROBE", "NO_PERIOD_STREAM", "NO_PROBE",
-                "NO_RANK_WRITER", "NO_TEXT_ROUNDS")
+                "NO_RANK_WRITER", "NO_TEXT_ROUNDS", "NO_MID")
 
 
 def _sync_routes(L):

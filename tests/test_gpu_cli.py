@@ -325,7 +325,14 @@ def test_container_with_post_stage(archon, tmp_path):
     assert r.returncode == 0, r.stdout
     r = subprocess.run([EXE, "e", "-b1m", str(raw), str(plain)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
-    assert np.fromfile(enc, np.uint8)[:2].tobytes() == b"RM" and os.path.getsize(enc) < os.path.getsize(plain)
+    head = np.fromfile(enc, np.uint8)[:10]
+    assert head[:2].tobytes() == b"RN" and os.path.getsize(enc) < os.path.getsize(plain)
+    assert int(head[2:6].view("<u4")[0]) == 1 << 20 and int(head[6:10].view("<u4")[0]) == 32 << 10      # block size, piece size
     r = subprocess.run([EXE, "d", "-b", str(enc), str(dec)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
     assert (np.fromfile(dec, np.uint8) == x).all()
+    # the first revision of the format ('RM': 4 MiB pieces, size not in the header) is recognised and refused, not mis-decoded
+    old = tmp_path / "old.rm"
+    np.concatenate([np.frombuffer(b"RM", np.uint8), head[2:6], np.fromfile(enc, np.uint8)[10:]]).tofile(old)
+    r = subprocess.run([EXE, "d", "-b", str(old), str(dec)], capture_output=True, text=True)
+    assert r.returncode != 0 and "first post-stage revision" in r.stderr

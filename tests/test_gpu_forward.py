@@ -342,6 +342,43 @@ def test_segmented_rounds(archon, oracle, name, monkeypatch):
     assert st["text_rounds"] + st["doubling_rounds"] > 0
 
 
+def _word_soup(n, vocab, word_len, seed, skew=1.3, alphabet=12):
+    """tokens drawn (Zipf-like) from a small vocabulary of fixed-length words over a small alphabet: after the first stage the
+    tied groups are the (word, offset) classes -- thousands to tens of thousands of rows each -- and every doubling round
+    splits them by the words in front: groups of every size class, each handing groups down to the smaller ones"""
+    rng = np.random.default_rng(seed)
+    words = rng.integers(97, 97 + alphabet, size=(vocab, word_len)).astype(np.uint8)
+    pr = 1.0 / np.arange(1, vocab + 1) ** skew
+    pr /= pr.sum()
+    toks = rng.choice(vocab, size=n // word_len + 1, p=pr)
+    return words[toks].reshape(-1)[:n].copy()
+
+
+@pytest.mark.parametrize("n,vocab,wl", [(3 << 20, 24, 16), ((5 << 20) + 12345, 7, 24), (1 << 21, 150, 9)])
+def test_mid_groups(archon, oracle, monkeypatch, n, vocab, wl):
+    """mid_rounds.hiph: groups of 1025 .. 16384 rows sorted by one workgroup in LDS, longer ones through the global sort,
+    survivors handed down from class to class (big -> large -> small -> S list) -- on both first-stage routes, with the
+    text rounds on and off, and against the old route (NO_MID) that sends every long group through the global sort."""
+    x = _word_soup(n, vocab, wl, 7 + vocab)
+    P, B, b0 = oracle.forward(x)
+    seen_mid = 0
+    for env in ({}, {"ARCHON_FORCE_PATH": "0"}, {"ARCHON_NO_TEXT_ROUNDS": "1"}, {"ARCHON_NO_RANK_WRITER": "1", "ARCHON_NO_PAIR_CHAINS": "1"},
+                {"ARCHON_NO_MID": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sa, bwt, base = archon.forward(x)
+        st = archon.stats()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert (sa == P).all(), (env, int(np.argmax(sa != P)))
+        assert (bwt == B).all() and base == b0, env
+        if "ARCHON_NO_MID" in env:
+            assert st["mid_items"] == 0
+        else:
+            seen_mid += st["mid_items"]
+    assert seen_mid > 0
+
+
 @pytest.mark.parametrize("sigma", [2, 3, 4, 5, 9, 16])
 @pytest.mark.parametrize("n", [70001, 1 << 20])
 def test_compacted_alphabet_streaming(archon, oracle, sigma, n):
