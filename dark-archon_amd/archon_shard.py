@@ -62,7 +62,12 @@ class GatherPipe:
         gdev = torch.device("cpu") if via_host else device
         self.lists = [None, None]
         if dist is not None and (rotate or rank == dst):
-            self.lists = [[torch.empty(payload_bytes, dtype=torch.uint8, device=gdev) for _ in range(world)] for _ in range(2)]
+            # A root's own payload is where it belongs already: its slot of the gathered list IS its payload buffer (torch's
+            # gather copies the root's input into that slot with copy_, which does nothing when both are one tensor), so a
+            # gather moves the world - 1 foreign payloads and nothing else -- 2 x 268 MB of HBM traffic less on the root per
+            # step it is root, all of a one-rank gather.
+            self.lists = [[self.outs[k] if (r == rank and not via_host) else torch.empty(payload_bytes, dtype=torch.uint8, device=gdev)
+                           for r in range(world)] for k in range(2)]
         self.pending = [None, None]          # per buffer: the work handle, once the helper has issued the gather
         self.issued = [None, None]           # per buffer: threading.Event set when the helper has issued it (or failed)
         self.error = None

@@ -15,6 +15,7 @@
 #include <atomic>
 #include <chrono>
 #include <stdlib.h>
+#include <thread>
 #include <vector>
 
 namespace archon {
@@ -33,12 +34,14 @@ void set_error(const char *fmt, ...)
 Route g_route;
 
 // ------------------------------------------------------------------ contexts
-// Two contexts per device (arena, staging buffers, stream, mailbox each): a host thread is bound to one of them at its
-// first call (round robin) and stays there, so one thread sees exactly the single-context behaviour (archon_hip_read_bwt
-// finds the BWT its own archon_hip_forward_keep left, archon_hip_get_stats its own last call), while two threads feeding
-// one GPU -- the container's workers (host/archon_container.cpp) -- overlap: block k's device-to-host copy runs beside
-// block k+1's host-to-device copy and kernels instead of the three standing in series behind one mutex.
-static constexpr int kMaxDev = 64, kCtxPerDev = 2;
+// Compute contexts of a device (arena, staging buffers, stream, mailbox each), created when first used: a host thread is
+// bound to one of the first two at its first call on the device and stays there, so one thread sees exactly the
+// single-context behaviour, while two threads feeding one GPU -- the container's workers (host/archon_container.cpp) --
+// overlap: block k's device-to-host copy runs beside block k+1's host-to-device copy and kernels instead of the three
+// standing in series behind one mutex.  Contexts 2 .. 7 exist for callers that name them (archon_hip_bind_context): the
+// batch entry points and the container run up to eight small blocks side by side -- a 4 MiB block is thirty launches of
+// a few microseconds each and cannot fill the chip or hide its own launch gaps.
+static constexpr int kMaxDev = 64, kCtxPerDev = 8, kCtxDefault = 2;      // contexts a device can have / that threads are dealt to by themselves
 static constexpr uint32_t kTieListCap = 1u << 20;
 static Ctx *g_ctx[kMaxDev][kCtxPerDev];
 static std::mutex g_ctx_mu;
@@ -61,7 +64,7 @@ static inline int keep_stats(Ctx *c, int rc)
 
 static int thread_slot(int dev)
 {
-    if (!t_slot[dev]) t_slot[dev] = (signed char)(1 + g_next_slot[dev].fetch_add(1u) % (unsigned)kCtxPerDev);
+    if (!t_slot[dev]) t_slot[dev] = (signed char)(1 + g_next_slot[dev].fetch_add(1u) % (unsigned)kCtxDefault);
     return t_slot[dev] - 1;
 }
 
@@ -386,6 +389,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     uint32_t chain_cool = 0;
     const bool chain_ok = n >= 4 && !route_off(kRtNoPairChains);
     const bool writer_ok = n >= (1u << 22) && !route_off(kRtNoRankWriter);
+    const uint32_t kWriterMinLog = n >= (1u << 26) ? (24u << 20) : n / 4;       // (small blocks keep exercising the writer in the tests)
     // One round over both lists: mode 0 keys on rank[s-h], mode 1 on the next four text bytes, modes 2 and 3 (hh = the period)
     // on the distance to the last period defect and on the rank of the item the key continues as behind it (rounds.hiph,
     // break_key / cont_key; rank table kept as in mode 0).
@@ -435,8 +439,8 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         }
         const uint32_t mid_entries = mid ? mm + mid_from_b : 0u;
         st.mid_items += mid_entries;
-        // many rank updates: dealt by item into windows of the table (rank_writer.hiph) instead of one random store each
-        const bool writer = mode != 1 && writer_ok && (uint64_t)ms + mb + mm >= (8u << 20);
+        // a long B list logs its rank updates by position for the rank writer (below) instead of storing them one by one
+        const bool writer = mode != 1 && writer_ok && nbig >= (8u << 20);
         // B: keys (the gather) now, global sort on (group, key) behind the S kernel -- which so runs while the host waits for
         // the sort's digit counts
         uint32_t shift = 32, gbits = 1;
@@ -523,22 +527,27 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             ++c->launches;
         }
         const bool flip = mid || mb != 0;           // (short groups that straddle a tile of k_b_finish's sweep stay in B for another round)
-        const uint32_t slog_cap = ms + mid_entries;         // what the S log can hold this round: the S kernel's and the mid kernels' updates
-        if (writer) {                           // the round's rank updates (S and mid: the log; B: k_b_finish's), now that every key has been read
-            B.rwb.r1 = reinterpret_cast<uint2 *>(b_log == reinterpret_cast<uint2 *>(kT) ? kS : kT);       // the key buffer that is not the B log
-            B.rwb.r2 = reinterpret_cast<uint2 *>(B.valA);
-            ARCHON_HIP_TRY(hipMemsetAsync(B.rwb.cnt1, 0, (rw::kMaxCoarse + rw::fine_buckets(n)) * sizeof(uint32_t), s));
-            if (slog_cap) hipLaunchKernelGGL(HIP_KERNEL_NAME(rw::k_part<1, 0>), dim3(div_up(slog_cap, rw::kTile)), dim3(rw::kLanes), 0, s, B.rlog, d_fu + 1, 0u, nullptr, nullptr, nullptr, B.rwb.r1, B.rwb.cnt1);
-            if (b_log) hipLaunchKernelGGL(HIP_KERNEL_NAME(rw::k_part<1, 0>), dim3(div_up(mb_round, rw::kTile)), dim3(rw::kLanes), 0, s, b_log, nullptr, mb_round, nullptr, nullptr, nullptr, B.rwb.r1, B.rwb.cnt1);
-            ARCHON_TRY(rw::write_back(s, B.rwb, n, B.rank, &c->launches));
-            c->launches += 2;
-        } else if (mode != 1 && slog_cap) {     // the S list's and the mid lists' rank updates, now that every key of the round has been read
-            hipLaunchKernelGGL(fwd::k_rank_apply, dim3(div_up(slog_cap, 256)), dim3(256), 0, s, B.rlog, d_fu + 1, B.rank);
-            ++c->launches;
-        }
+        // The round's counters come to the host BEFORE its rank updates are applied: how the S and mid lists' updates (the log) are
+        // written depends on how many there are, and the host has to wait for these counters anyway.
         if (mid) ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 4200, B.mc, fwd::kMcWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_fu, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        const uint32_t nlog = mode != 1 ? c->h_mail[1] : 0u;
+        // Rank updates, now that every key of the round has been read.  Dealt by item into windows of the table (rank_writer.hiph:
+        // two partition sweeps + one window write, 0.6 ms whatever the number + 11 ps per update) they beat one random store each
+        // (32 ps) from about 28 M updates on; the B list's updates are logged by position whenever that list is long (b_log).
+        if (b_log || (writer_ok && mode != 1 && nlog >= kWriterMinLog)) {
+            B.rwb.r1 = reinterpret_cast<uint2 *>(b_log == reinterpret_cast<uint2 *>(kT) ? kS : kT);       // the key buffer that is not the B log
+            B.rwb.r2 = reinterpret_cast<uint2 *>(B.valA);
+            ARCHON_HIP_TRY(hipMemsetAsync(B.rwb.cnt1, 0, (rw::kMaxCoarse + rw::fine_buckets(n)) * sizeof(uint32_t), s));
+            if (nlog) hipLaunchKernelGGL(HIP_KERNEL_NAME(rw::k_part<1, 0>), dim3(div_up(nlog, rw::kTile)), dim3(rw::kLanes), 0, s, B.rlog, nullptr, nlog, nullptr, nullptr, nullptr, B.rwb.r1, B.rwb.cnt1);
+            if (b_log) hipLaunchKernelGGL(HIP_KERNEL_NAME(rw::k_part<1, 0>), dim3(div_up(mb_round, rw::kTile)), dim3(rw::kLanes), 0, s, b_log, nullptr, mb_round, nullptr, nullptr, nullptr, B.rwb.r1, B.rwb.cnt1);
+            ARCHON_TRY(rw::write_back(s, B.rwb, n, B.rank, &c->launches));
+            c->launches += 2;
+        } else if (nlog) {
+            hipLaunchKernelGGL(fwd::k_rank_apply, dim3(div_up(nlog, 256)), dim3(256), 0, s, B.rlog, d_fu + 1, B.rank);
+            ++c->launches;
+        }
         ms = c->h_mail[0];
         mb = mb_round ? c->h_mail[2] : 0u;
         bgroups = c->h_mail[3];
@@ -1802,6 +1811,81 @@ int archon_hip_radix_scatter(const uint8_t *src, size_t n, uint8_t *dst, int dev
     (void)hipFree(d_a);
     (void)hipFree(d_b);
     return rc;
+}
+
+// ---- several small blocks per call ---------------------------------------------------------------------------------------
+// x3's default block is 4 MiB (bwt/final/x3/archon.c:100,108).  One such block is thirty launches of a few microseconds and
+// one or two host round trips: alone on the device it runs at a tenth of the rate of a 256 MiB block.  A batch call deals its
+// blocks to `workers` host threads, each bound to a compute context of its own (stream, arena, staging buffers): the
+// blocks' kernels, copies and launch gaps overlap.  workers <= 0: chosen from the largest block (8 up to 4 MiB, 4 up to
+// 16 MiB, 2 beyond).  Blocks are independent; the first error stops the rest and is returned.
+static int batch_workers(const uint32_t *n, uint32_t count, int workers)
+{
+    uint32_t mx = 0;
+    for (uint32_t i = 0; i < count; ++i) mx = n[i] > mx ? n[i] : mx;
+    int w = workers > 0 ? workers : (mx <= (4u << 20) ? 8 : mx <= (16u << 20) ? 4 : 2);
+    if (w > kCtxPerDev) w = kCtxPerDev;
+    if ((uint32_t)w > count) w = (int)count;
+    return w < 1 ? 1 : w;
+}
+
+extern "C++" {
+template <class Fn>
+static int run_batch(uint32_t count, int w, int dev, Fn fn)
+{
+    std::atomic<int> rc{ARCHON_OK};
+    std::atomic<uint32_t> next{0};
+    std::mutex emu;
+    char emsg[sizeof t_err] = "";
+    std::vector<std::thread> th;
+    for (int t = 0; t < w; ++t)
+        th.emplace_back([&, t] {
+            (void)archon_hip_bind_context(dev, t);
+            for (;;) {
+                const uint32_t i = next.fetch_add(1u);
+                if (i >= count || rc.load() != ARCHON_OK) return;
+                const int r = fn(i);
+                if (r != ARCHON_OK) {
+                    std::lock_guard<std::mutex> lk(emu);
+                    if (rc.load() == ARCHON_OK) { rc.store(r); snprintf(emsg, sizeof emsg, "block %u: %s", i, t_err); }
+                    return;
+                }
+            }
+        });
+    for (auto &t : th) t.join();
+    if (rc.load() != ARCHON_OK) set_error("%s", emsg);
+    return rc.load();
+}
+}   // extern "C++"
+
+int archon_hip_forward_batch(const uint8_t *const *x, const uint32_t *n, uint32_t count, uint8_t *const *bwt, uint32_t *base_id, int dev, int workers)
+{
+    if (!x || !n || !bwt || !base_id) { set_error("null pointer"); return ARCHON_E_ARG; }
+    if (count == 0) return ARCHON_OK;
+    return run_batch(count, batch_workers(n, count, workers), dev, [&](uint32_t i) { return archon_hip_forward(x[i], n[i], nullptr, bwt[i], base_id + i, dev); });
+}
+
+int archon_hip_inverse_batch(const uint8_t *const *bwt, const uint32_t *n, const uint32_t *base_id, uint32_t count, uint8_t *const *x_out, int dev, int workers)
+{
+    if (!bwt || !n || !base_id || !x_out) { set_error("null pointer"); return ARCHON_E_ARG; }
+    if (count == 0) return ARCHON_OK;
+    return run_batch(count, batch_workers(n, count, workers), dev, [&](uint32_t i) { return archon_hip_inverse(bwt[i], n[i], base_id[i], x_out[i], dev); });
+}
+
+int archon_hip_forward_batch_dev(const uint8_t *const *d_x, const uint32_t *n, uint32_t count, uint32_t *const *d_sa_or_null, uint8_t *const *d_bwt,
+                                 uint32_t *const *d_base_id, int dev, int workers)
+{
+    if (!d_x || !n || !d_bwt || !d_base_id) { set_error("null pointer"); return ARCHON_E_ARG; }
+    if (count == 0) return ARCHON_OK;
+    return run_batch(count, batch_workers(n, count, workers), dev,
+                     [&](uint32_t i) { return archon_hip_forward_dev(d_x[i], n[i], d_sa_or_null ? d_sa_or_null[i] : nullptr, d_bwt[i], d_base_id[i], dev, nullptr); });
+}
+
+int archon_hip_inverse_batch_dev(const uint8_t *const *d_bwt, const uint32_t *n, const uint32_t *base_id, uint32_t count, uint8_t *const *d_x_out, int dev, int workers)
+{
+    if (!d_bwt || !n || !base_id || !d_x_out) { set_error("null pointer"); return ARCHON_E_ARG; }
+    if (count == 0) return ARCHON_OK;
+    return run_batch(count, batch_workers(n, count, workers), dev, [&](uint32_t i) { return archon_hip_inverse_dev(d_bwt[i], n[i], base_id[i], d_x_out[i], dev, nullptr); });
 }
 
 int archon_hip_reserve(uint32_t n, int dev, size_t *bytes_or_null)

@@ -110,10 +110,11 @@ struct Pipe {
     }
 };
 
-// Two workers per GPU: the library keeps two contexts per device and binds a host thread to one of them, so worker w
-// (blocks w, w + 2G, w + 4G, ... on GPU w mod G -- still block b on GPU b mod G) moves its block over PCIe while its
-// twin's kernels run.
-constexpr int kWorkersPerGpu = 2;
+// Several workers per GPU, each bound to a compute context of its own (archon_hip_bind_context): worker w (blocks w, w + WG,
+// w + 2WG, ... on GPU w mod G -- still block b on GPU b mod G) moves its block over PCIe while its twins' kernels run.
+// Small blocks (x3's default is 4 MiB, final/x3/archon.c:100) cannot fill the chip one or two at a time -- a block is
+// thirty launches of a few microseconds -- so they get more workers, each on a context of its own (up to the library's eight).
+static int workers_per_gpu(uint32_t bsize) { return bsize <= (4u << 20) ? 8 : bsize <= (16u << 20) ? 4 : 2; }
 
 // worker `first` of `step`: blocks first, first + step, ... on GPU `dev`
 template <class Work>
@@ -185,6 +186,7 @@ int archon_container_encode(FILE *fi, FILE *fo, uint32_t bsize, int ndev, int po
     if (post && fwrite(&piece, 4, 1, fo) != 1) return -3;
     Pipe p;
     const size_t out_cap = post ? post_slot_bytes(bsize) : (size_t)bsize + 4;
+    const int kWorkersPerGpu = workers_per_gpu(bsize);
     if (!p.alloc((kWorkersPerGpu + 2) * ndev, (size_t)bsize + 4, out_cap)) return ARCHON_E_NOMEM;
 
     std::thread reader([&] {
@@ -243,6 +245,7 @@ int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out)
     const size_t kPiece = piece;
     if (bsize_out) *bsize_out = bsize;
     Pipe p;
+    const int kWorkersPerGpu = workers_per_gpu(bsize);
     if (!p.alloc((kWorkersPerGpu + 2) * ndev, (size_t)bsize + 4)) return ARCHON_E_NOMEM;
 
     std::thread reader([&] {

@@ -30,6 +30,7 @@ SYMBOLS = [
     "archon_hip_block_validate", "archon_hip_block_stats", "archon_hip_validate_keep",
     "archon_hip_bind_context", "archon_hip_context_of_thread", "archon_hip_set_option", "archon_hip_get_option",
     "archon_hip_post_bound", "archon_hip_post_encode_dev", "archon_hip_forward_post", "archon_hip_validate_resident_dev",
+    "archon_hip_forward_batch", "archon_hip_inverse_batch", "archon_hip_forward_batch_dev", "archon_hip_inverse_batch_dev",
 ]
 
 
@@ -105,6 +106,10 @@ def load():
         "archon_hip_context_of_thread": [i32],
         "archon_hip_set_option": [i32, ctypes.c_char_p, ctypes.c_long],
         "archon_hip_get_option": [i32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_long)],
+        "archon_hip_forward_batch": [vp, vp, u32, vp, vp, i32, i32],
+        "archon_hip_inverse_batch": [vp, vp, vp, u32, vp, i32, i32],
+        "archon_hip_forward_batch_dev": [vp, vp, u32, vp, vp, vp, i32, i32],
+        "archon_hip_inverse_batch_dev": [vp, vp, vp, u32, vp, i32, i32],
         "archon_hip_post_encode_dev": [vp, u32, vp, sz, vp, i32, vp],
         "archon_hip_forward_post": [vp, u32, vp, sz, vp, vp, i32],
     }.items():
@@ -348,3 +353,41 @@ def validate_resident_dev(x_t, sa_t, bwt_t, base_id):
     dev = x_t.device.index or 0
     return bool(_check(lib().archon_hip_validate_resident_dev(ctypes.c_void_p(x_t.data_ptr()), x_t.numel(), ctypes.c_void_p(sa_t.data_ptr()),
                                                               ctypes.c_void_p(bwt_t.data_ptr()), int(base_id), dev, _stream_ptr())))
+
+
+def _ptr_array(ptrs):
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+def forward_batch(blocks, dev=0, workers=0):
+    """several small blocks per call (archon_hip_forward_batch): list of uint8 arrays -> list of (bwt, base_id)"""
+    xs = [np.ascontiguousarray(b, dtype=np.uint8) for b in blocks]
+    outs = [np.empty(b.size, np.uint8) for b in xs]
+    ns = (ctypes.c_uint32 * len(xs))(*[b.size for b in xs])
+    base = (ctypes.c_uint32 * len(xs))()
+    _check(lib().archon_hip_forward_batch(_ptr_array([b.ctypes.data for b in xs]), ns, len(xs), _ptr_array([o.ctypes.data for o in outs]), base, dev, workers))
+    return [(o, int(base[i])) for i, o in enumerate(outs)]
+
+
+def inverse_batch(bwts, bases, dev=0, workers=0):
+    bs = [np.ascontiguousarray(b, dtype=np.uint8) for b in bwts]
+    outs = [np.empty(b.size, np.uint8) for b in bs]
+    ns = (ctypes.c_uint32 * len(bs))(*[b.size for b in bs])
+    base = (ctypes.c_uint32 * len(bs))(*[int(v) for v in bases])
+    _check(lib().archon_hip_inverse_batch(_ptr_array([b.ctypes.data for b in bs]), ns, base, len(bs), _ptr_array([o.ctypes.data for o in outs]), dev, workers))
+    return outs
+
+
+def forward_batch_dev(x_ts, bwt_ts, base_ts, sa_ts=None, workers=0):
+    dev = x_ts[0].device.index or 0
+    ns = (ctypes.c_uint32 * len(x_ts))(*[t.numel() for t in x_ts])
+    sa = _ptr_array([t.data_ptr() if t is not None else None for t in sa_ts]) if sa_ts is not None else None
+    _check(lib().archon_hip_forward_batch_dev(_ptr_array([t.data_ptr() for t in x_ts]), ns, len(x_ts), sa, _ptr_array([t.data_ptr() for t in bwt_ts]),
+                                              _ptr_array([t.data_ptr() for t in base_ts]), dev, workers))
+
+
+def inverse_batch_dev(bwt_ts, bases, out_ts, workers=0):
+    dev = bwt_ts[0].device.index or 0
+    ns = (ctypes.c_uint32 * len(bwt_ts))(*[t.numel() for t in bwt_ts])
+    base = (ctypes.c_uint32 * len(bwt_ts))(*[int(v) for v in bases])
+    _check(lib().archon_hip_inverse_batch_dev(_ptr_array([t.data_ptr() for t in bwt_ts]), ns, base, len(bwt_ts), _ptr_array([t.data_ptr() for t in out_ts]), dev, workers))

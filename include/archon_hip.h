@@ -147,6 +147,18 @@ int archon_hip_radix_scatter_dev(const uint8_t *d_src, size_t n, uint8_t *d_dst,
 /* d_items: n/2 + 8 words; *n1 is a HOST pointer (the count is needed on the host to size the launches) */
 int archon_hip_lms_select_dev(const uint8_t *d_x, uint32_t n, uint32_t *d_count256, uint32_t *d_items, uint32_t *n1, int dev, void *stream);
 
+/* ---- several small blocks per call (x3's block loop, bwt/final/x3/archon.c:120-142, at its default 4 MiB block) ------------
+ * One small block cannot fill the chip: a batch call deals blocks x[0..count) of n[i] bytes to `workers` host threads inside
+ * the library, each on a compute context of its own, so that the blocks' copies, kernels and launch gaps overlap
+ * (workers <= 0: 8 for blocks up to 4 MiB, 4 up to 16 MiB, 2 beyond; at most 8).  Every block is an independent a7
+ * transform with its own primary index; the first error stops the batch and is returned.  Host pointers; the _dev
+ * forms take device pointers (d_sa_or_null: NULL, or one pointer per block, each NULL or a buffer of n[i] words). */
+int archon_hip_forward_batch(const uint8_t *const *x, const uint32_t *n, uint32_t count, uint8_t *const *bwt, uint32_t *base_id, int dev, int workers);
+int archon_hip_inverse_batch(const uint8_t *const *bwt, const uint32_t *n, const uint32_t *base_id, uint32_t count, uint8_t *const *x_out, int dev, int workers);
+int archon_hip_forward_batch_dev(const uint8_t *const *d_x, const uint32_t *n, uint32_t count, uint32_t *const *d_sa_or_null, uint8_t *const *d_bwt,
+                                 uint32_t *const *d_base_id, int dev, int workers);
+int archon_hip_inverse_batch_dev(const uint8_t *const *d_bwt, const uint32_t *n, const uint32_t *base_id, uint32_t count, uint8_t *const *d_x_out, int dev, int workers);
+
 /* ---- workspace / lifetime ---------------------------------------------------- */
 
 /* Pre-size the arena of the calling thread's context on `dev` for blocks up to n bytes (optional; the arena grows on
@@ -154,7 +166,7 @@ int archon_hip_lms_select_dev(const uint8_t *d_x, uint32_t n, uint32_t *d_count2
  * Returns bytes reserved via *bytes_or_null. */
 int archon_hip_reserve(uint32_t n, int dev, size_t *bytes_or_null);
 
-/* Bind the calling thread to compute context `slot` (0 or 1) of `dev` -- what a pool of workers does so that the two
+/* Bind the calling thread to compute context `slot` (0 .. 7; threads that do not ask are dealt to 0 and 1) of `dev` -- what a pool of workers does so that the two
  * workers of one GPU never share a context whatever order they start in (host/archon_container.cpp: worker w of G GPUs
  * drives GPU w mod G on context w / G).  Without it the k-th thread to reach a device gets context k mod 2 of that
  * device.  archon_hip_context_of_thread returns the binding (and makes the default one if there is none yet). */

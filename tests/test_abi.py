@@ -191,7 +191,7 @@ def test_options_and_context_binding_need_no_gpu():
     t.start()
     t.join()
     assert res["a"][0] == 1 and res["a"][1] == 0
-    assert L.archon_hip_bind_context(42, 2) < 0 and L.archon_hip_bind_context(-1, 0) < 0
+    assert L.archon_hip_bind_context(42, 8) < 0 and L.archon_hip_bind_context(-1, 0) < 0 and L.archon_hip_bind_context(42, 7) == 0
 
 
 def test_bench_uses_the_product_api_only():

@@ -25,6 +25,10 @@ def run(threads, want_sa, inverse=False):
     bases = [0] * threads
 
     def fwd(t, k):
+        # (every thread of a run -- warm-up and timed alike -- names its context: thread t of a run always computes on context t, so
+        #  the timed threads find the arenas and staging buffers their warm-up twins grew.  Round 3's harness left the binding to
+        #  the order the threads were created in; its one-thread figure (19.7 ms) was a timed thread on a cold context.)
+        L.archon_hip_bind_context(0, t)
         x, sa, bwt, back = bufs[t]
         for _ in range(k):
             base = ctypes.c_uint32(0)
@@ -33,6 +37,7 @@ def run(threads, want_sa, inverse=False):
             bases[t] = base.value
 
     def inv(t, k):
+        L.archon_hip_bind_context(0, t)
         x, sa, bwt, back = bufs[t]
         for _ in range(k):
             assert L.archon_hip_inverse(bwt.ctypes.data, n, bases[t], back.ctypes.data, 0) == 0
