@@ -43,6 +43,7 @@ Route g_route;
 // a few microseconds each and cannot fill the chip or hide its own launch gaps.
 static constexpr int kMaxDev = 64, kCtxPerDev = 8, kCtxDefault = 2;      // contexts a device can have / that threads are dealt to by themselves
 static constexpr uint32_t kTieListCap = 1u << 20;
+static constexpr uint32_t kSmallBlock = 8u << 20;       // blocks below this take the byte count + LSB passes instead of the streaming stage
 static Ctx *g_ctx[kMaxDev][kCtxPerDev];
 static std::mutex g_ctx_mu;
 // The binding is per (thread, device): the k-th thread that comes to device d takes context k mod 2 OF THAT DEVICE (one
@@ -410,6 +411,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         // sort below.  (Text rounds keep round 3's path: they run on small sets.)
         const bool mid = mode != 1 && !route_off(kRtNoMid);
         uint32_t nS = mdS, nL = mdL, nbig = mb, nbig_groups = bgroups, mid_from_b = 0;
+        bool split = false;                         // the B list was dealt out: its big groups go to the global sort compacted
         const int nxt = cur ^ 1;
         if (mid) {
             // the next list starts empty: no groups, its items from the top of the buffer downwards
@@ -417,10 +419,13 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             ARCHON_HIP_TRY(hipMemcpyAsync(B.mc + fwd::kMcSmall + nxt, c->h_mail + 4200, sizeof(uint32_t), hipMemcpyHostToDevice, s));
             ARCHON_HIP_TRY(hipMemcpyAsync(B.mc + fwd::kMcLarge + nxt, c->h_mail + 4200, sizeof(uint32_t), hipMemcpyHostToDevice, s));
             ARCHON_HIP_TRY(hipMemcpyAsync(B.mc + fwd::kMcTop + nxt, c->h_mail + 4201, sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            if (mb) {
+            // (a B list whose groups average four times the largest mid group -- a periodic block with defects: one group per phase of
+            //  the period -- goes to the global sort as it is: the two sweeps that would deal it out find nothing to hand over)
+            if (mb && (uint64_t)bgroups * (4u * fwd::kMidLargeCap) > mb) {
                 const uint32_t tiles = div_up(mb, fwd::kBfTile);
                 ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
                 ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
+                split = true;
                 hipLaunchKernelGGL(fwd::k_b_dir, dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], mb, B.gdir_off, B.gdir_row, fg_status, B.sc.d_ticket, B.sc.d_err, B.mc, (uint32_t)mid_dir_cap(n));
                 hipLaunchKernelGGL(fwd::k_b_plan, dim3(1), dim3(1024), 0, s, B.gdir_off, B.gdir_row, mb, B.gcls, B.gbig, B.dirS[cur], B.dirL[cur], B.mc, (uint32_t)cur,
                                    (uint32_t)fwd::kMidSmallCap, (uint32_t)fwd::kMidLargeCap, (uint32_t)mid_dir_cap(n), B.sc.d_err);
@@ -448,7 +453,6 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         while ((uint64_t)nbig_groups >> gbits) ++gbits;                             // bits of a group number of the (big) B list
         const uint32_t nbytes = (shift + gbits + 7) / 8;
         const uint32_t mb_round = nbig;
-        const bool split = mid && mb != 0;
         if (nbig) {
             st.seg_big_items += nbig;
             const uint32_t tiles = div_up(mb, fwd::kBfTile);
@@ -944,6 +948,26 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     int path;
     int Q = 1;                                   // symbols per key byte on the streaming path
     const bool probe = forced < 0 && !route_off(kRtNoProbe);
+    // Small blocks (the container's default is 4 MiB, bwt/final/x3/archon.c:100): the streaming stage is built for blocks that fill
+    // the chip -- its two-byte count keeps 128 KiB of counters per workgroup on all 256 CUs, its bucket sort launches 65 536
+    // workgroups -- and costs 0.7 ms whatever the block holds.  Below kSmallBlock a block takes a plain byte count and the LSB
+    // passes, whose cost follows its size.
+    const uint32_t small_limit = g_route.small_block >= 0 ? (uint32_t)g_route.small_block : kSmallBlock;
+    const bool small_block = forced < 0 && n >= 8 && n < small_limit;
+    if (small_block) {
+        ARCHON_TRY(launch_hist256(s, d_x, n, d_counts, n));
+        ++c->launches;
+        e1 = tm.mark();
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 128, d_counts, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 512, d_x + (n - 1), 1, hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        // (in the form the two-byte count leaves its column sums in -- the bytes x[0 .. n-2] and the 0xFF in front of x[0] --
+        //  which is what the code below undoes)
+        c->h_mail[128 + (c->h_mail[512] & 0xFFu)] -= 1u;
+        c->h_mail[128 + 0xFFu] += 1u;
+        have_byte_counts = true;
+        path = 0;
+    } else {
     ARCHON_TRY(count16(1, d_x, forced == 1, probe));
     if (forced == 0) {
         ARCHON_TRY(count_wait());
@@ -951,6 +975,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     } else {
         ARCHON_TRY(streaming(1, d_x));
         path = (forced == 1 || (uint64_t)big_items * 2 <= n) ? 1 : 0;
+    }
     }
     uint32_t sigma = 0, bits = 8;
     uint8_t *d_lut = reinterpret_cast<uint8_t *>(small + 900);
@@ -1000,7 +1025,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             if (!route_off(kRtNoPeriodHint)) period_hint = pp;     // the run shortcut need not sample neighbour gaps for it
             const bool count_ok = forced < 0 && !h_ctl.suspect;
             const bool single_runs = pp <= 2 || (count_ok && (uint64_t)h_ctl.max_bucket * 2 * pp <= (uint64_t)n * 3);
-            if (forced < 0 && single_runs && !route_off(kRtNoPeriodStream)) {
+            if (forced < 0 && single_runs && !small_block && !route_off(kRtNoPeriodStream)) {
                 period_hint = pp;               // (the streaming passes keep no order inside a bucket: gap sampling would not work)
                 ARCHON_TRY(count16(1, d_x, true, false, true));
                 ARCHON_TRY(streaming(1, d_x, true));
@@ -1043,7 +1068,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         if (sigma <= 16 && !route_off(kRtNoPack)) {
             memcpy(c->h_mail + 1024, h_lut, 256);
             ARCHON_HIP_TRY(hipMemcpyAsync(d_lut, c->h_mail + 1024, 256, hipMemcpyHostToDevice, s));
-            if (sigma >= 2 && forced < 0 && !route_off(kRtNoPackStream)) {
+            if (sigma >= 2 && forced < 0 && !small_block && !route_off(kRtNoPackStream)) {
                 const int q = bits == 1 ? 8 : bits == 2 ? 4 : 2;
                 const dim3 grid(div_up(div_up(n, 16), 256)), block(256);
                 if (q == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_build_y<8>), grid, block, 0, s, d_x, n, d_lut, B.y);
@@ -1975,6 +2000,7 @@ int archon_hip_test_route(const char *name, long value)
         g_route.pass_ranges = (uint32_t)value;
         return ARCHON_OK;
     }
+    if (!strcmp(name, "SMALL_BLOCK")) { g_route.small_block = value; return ARCHON_OK; }
     if (!strcmp(name, "INV_SLAB")) { g_route.inv_slab = value > 0 ? (uint32_t)value : 0u; return ARCHON_OK; }
     if (!strcmp(name, "INV_SBITS")) { g_route.inv_sbits = (int)value; return ARCHON_OK; }
     if (!strcmp(name, "INV_WALK_WGS")) { g_route.inv_walk_wgs = (int)value; return ARCHON_OK; }

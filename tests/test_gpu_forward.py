@@ -342,6 +342,22 @@ def test_segmented_rounds(archon, oracle, name, monkeypatch):
     assert st["text_rounds"] + st["doubling_rounds"] > 0
 
 
+@pytest.mark.small_block_default
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 255, 4097, 65536, 1 << 20, (4 << 20) + 3, (8 << 20) - 1, 8 << 20])
+def test_small_blocks_product_route(archon, oracle, n):
+    """blocks below 8 MiB on the product's own route (byte count + LSB passes, no two-byte count): every shape, the sizes
+    around the limits (n < 8: keys made by k_init_keys; the last size below the limit; the first one that streams)"""
+    for shape in ("random", "text", "dna", "a", "ab", "motif", "prose"):
+        if (n >= (1 << 22) and shape not in ("random", "text", "dna")) or (n < 255 and shape == "prose"):
+            continue
+        x = S.gen_shape(shape, n)
+        P, B, b0 = oracle.forward(x)
+        sa, bwt, base = archon.forward(x)
+        assert (sa == P).all() and (bwt == B).all() and base == b0, (shape, n)
+        if 8 <= n < (8 << 20):
+            assert archon.stats()["path"] == 0, (shape, n)
+
+
 def _word_soup(n, vocab, word_len, seed, skew=1.3, alphabet=12):
     """tokens drawn (Zipf-like) from a small vocabulary of fixed-length words over a small alphabet: after the first stage the
     tied groups are the (word, offset) classes -- thousands to tens of thousands of rows each -- and every doubling round

@@ -34,6 +34,19 @@ def _sha(*parts):
     return h.hexdigest()
 
 
+@pytest.mark.small_block_default
+@pytest.mark.parametrize("case", GOLDEN["cases"], ids=lambda c: "%s-%d" % (c["shape"], c["n"]))
+def test_hip_vs_reference_small_product_route(archon, case):
+    """the same cases on the route the product takes by itself: blocks below 8 MiB skip the streaming stage"""
+    x = S.gen_shape(case["shape"], case["n"])
+    sa, bwt, base = archon.forward(x)
+    assert base == case["base_id"]
+    assert _sha(np.ascontiguousarray(sa, "<u4")) == case["sha256_P"]
+    assert _sha(bwt, int(base).to_bytes(4, "little")) == case["sha256_bwt_base"]
+    if 8 <= case["n"] < (8 << 20):
+        assert archon.stats()["path"] == 0
+
+
 @pytest.mark.parametrize("case", GOLDEN["cases"], ids=lambda c: "%s-%d" % (c["shape"], c["n"]))
 def test_hip_vs_reference_small(archon, case):
     """every committed reference case up to 16 Mi, through the host-buffer C ABI"""
