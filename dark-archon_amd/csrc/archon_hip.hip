@@ -419,9 +419,9 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             ARCHON_HIP_TRY(hipMemcpyAsync(B.mc + fwd::kMcSmall + nxt, c->h_mail + 4200, sizeof(uint32_t), hipMemcpyHostToDevice, s));
             ARCHON_HIP_TRY(hipMemcpyAsync(B.mc + fwd::kMcLarge + nxt, c->h_mail + 4200, sizeof(uint32_t), hipMemcpyHostToDevice, s));
             ARCHON_HIP_TRY(hipMemcpyAsync(B.mc + fwd::kMcTop + nxt, c->h_mail + 4201, sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            // (a B list whose groups average four times the largest mid group -- a periodic block with defects: one group per phase of
+            // (a B list whose groups average twice the largest mid group -- a periodic block with defects: one group per phase of
             //  the period -- goes to the global sort as it is: the two sweeps that would deal it out find nothing to hand over)
-            if (mb && (uint64_t)bgroups * (4u * fwd::kMidLargeCap) > mb) {
+            if (mb && (uint64_t)bgroups * (2u * fwd::kMidLargeCap) > mb) {
                 const uint32_t tiles = div_up(mb, fwd::kBfTile);
                 ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
                 ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
@@ -841,12 +841,11 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         else if (Q == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<2>), grid, block, 0, s, src, n, B.h16part, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
         else if (Q == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<4>), grid, block, 0, s, src, n, B.h16part, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.h16part, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
-        hipLaunchKernelGGL(bs::k_hist16_sum, dim3(32, 8), dim3(256), 0, s, B.hist16, B.h16part, nparts);
-        hipLaunchKernelGGL(bs::k_rows_total, dim3(256), dim3(256), 0, s, B.hist16, B.prep, (uint32_t)bs::kLsCap);
+        static_assert(bs::kMaxRanges <= 1024, "four ranges per lane in the column half of k_rows_sum_total");
+        hipLaunchKernelGGL(bs::k_rows_sum_total, dim3(512), dim3(256), 0, s, B.hist16, B.h16part, nparts, B.prep, (uint32_t)bs::kLsCap, rhist, R);
         hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep, force_stream ? 1u : 0u, allow_aligned, d_ctl, (uint32_t)kTieListCap, n);
-        hipLaunchKernelGGL(bs::k_col_prefix, dim3(256), dim3(1024), 0, s, rhist, R, &B.prep->skip);
         ARCHON_HIP_TRY(hipGetLastError());
-        c->launches += 5;
+        c->launches += 3;
         e1 = tm.mark();
         return ARCHON_OK;
     };
