@@ -110,7 +110,9 @@ class GatherPipe:
         if self.error is not None:
             raise self.error
         if self.pending[k] is not None:
-            self.pending[k].wait()
+            # (a gather that has completed -- the usual case: it was issued two steps ago -- needs no wait on the stream)
+            if not self.pending[k].is_completed():
+                self.pending[k].wait()
             self.pending[k] = None
 
     def next_buffer(self):
