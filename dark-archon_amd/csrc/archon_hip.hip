@@ -202,6 +202,7 @@ static size_t forward_arena_bytes(uint32_t n, int dev)
     add(4 * 4 * (mid_dir_cap(n) + 8));                          // directory of the B list: first entry, first row, place in the big list, number among the big groups
     for (int i = 0; i < 4; ++i) add(16 * (mid_dir_cap(n) + 8)); // directories of the two mid classes, double-buffered
     add(4 * fwd::kMcWords);
+    add(4 * ((size_t)n / fwd::kBfTile + 8)); add(4 * ((size_t)n / fwd::kBfTile / 32 + 8));       // per tile of the B list: groups before it, "holds big entries"
     return b + 4096;
 }
 
@@ -220,7 +221,7 @@ struct FwdBuf {
     uint4 *trash;              // write-only trash lines of the pass workgroups (passes.hiph, emit_rec)
     rs::Scratch sc;
     // mid_rounds.hiph: directory of the B list, the class directories of the mid lists (double-buffered), the counters
-    uint32_t *gdir_off, *gdir_row, *gcls, *gbig, *mc;
+    uint32_t *gdir_off, *gdir_row, *gcls, *gbig, *mc, *tile_g0, *tile_big;
     uint4 *dirS[2], *dirL[2];
 };
 
@@ -426,9 +427,9 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
                 ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
                 ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ticket, 0, sizeof(uint32_t), s));
                 split = true;
-                hipLaunchKernelGGL(fwd::k_b_dir, dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], mb, B.gdir_off, B.gdir_row, fg_status, B.sc.d_ticket, B.sc.d_err, B.mc, (uint32_t)mid_dir_cap(n));
+                hipLaunchKernelGGL(fwd::k_b_dir, dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], mb, B.gdir_off, B.gdir_row, fg_status, B.sc.d_ticket, B.sc.d_err, B.mc, (uint32_t)mid_dir_cap(n), B.tile_g0);
                 hipLaunchKernelGGL(fwd::k_b_plan, dim3(1), dim3(1024), 0, s, B.gdir_off, B.gdir_row, mb, B.gcls, B.gbig, B.dirS[cur], B.dirL[cur], B.mc, (uint32_t)cur,
-                                   (uint32_t)fwd::kMidSmallCap, (uint32_t)fwd::kMidLargeCap, (uint32_t)mid_dir_cap(n), B.sc.d_err);
+                                   (uint32_t)fwd::kMidSmallCap, (uint32_t)fwd::kMidLargeCap, (uint32_t)mid_dir_cap(n), B.sc.d_err, B.tile_big);
                 ARCHON_HIP_TRY(hipGetLastError());
                 ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 4200, B.mc, fwd::kMcWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                 ARCHON_HIP_TRY(hipStreamSynchronize(s));
@@ -463,7 +464,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
                                             shift, mb, kT, vT, fg_status, B.sc.d_ticket, B.sc.d_err, B.sc.d_ghist, nbytes, B.brk, cert, okey)
 #define ARCHON_B_KEYS_SPLIT(M) hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd::k_b_keys_split<M>), dim3(tiles), dim3(256), 0, s, B.upos[cur], B.ug[cur], B.uitem[cur], B.rank, d_x, hh, n, \
                                             shift, mb, kT, vT, fg_status, B.sc.d_ticket, B.sc.d_err, B.sc.d_ghist, nbytes, B.brk, cert, okey, \
-                                            B.gdir_off, B.gcls, B.gbig, B.upos[nxt], B.ug[nxt])
+                                            B.gdir_off, B.gcls, B.gbig, B.upos[nxt], B.ug[nxt], B.tile_g0, B.tile_big)
             if (split) {
                 if (mode == 0) ARCHON_B_KEYS_SPLIT(0);
                 else if (mode == 2) ARCHON_B_KEYS_SPLIT(2);
@@ -770,7 +771,9 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         B.dirL[i] = c->alloc<uint4>(mid_dir_cap(n) + 8);
     }
     B.mc = c->alloc<uint32_t>(fwd::kMcWords);
-    if (!B.small || !B.rlog || !B.rwb.cnt1 || !B.mc) {
+    B.tile_g0 = c->alloc<uint32_t>((size_t)n / fwd::kBfTile + 8);
+    B.tile_big = c->alloc<uint32_t>((size_t)n / fwd::kBfTile / 32 + 8);
+    if (!B.small || !B.rlog || !B.rwb.cnt1 || !B.mc || !B.tile_big) {
         set_error("arena exhausted");
         return ARCHON_E_NOMEM;
     }
@@ -1673,6 +1676,63 @@ static int post_run(Ctx *c, hipStream_t s, const uint8_t *d_bwt, uint32_t n, uin
     if (total < 4 + 4ull * np || total > post::block_bound(n)) { set_error("post stage: stream length %llu out of bounds", total); return ARCHON_E_INTERNAL; }
     *out_bytes = (size_t)total;
     c->launches += 2;
+    return ARCHON_OK;
+}
+
+// stream -> BWT (k_post_offsets, k_post_decode); *n_out = the block's length.  Synchronises the stream.
+static int post_decode_run(Ctx *c, hipStream_t s, const uint8_t *d_in, size_t in_bytes, uint8_t *d_bwt, uint32_t cap, uint32_t *n_out)
+{
+    const size_t np_max = (size_t)cap / post::kPiece + 2;
+    ARCHON_TRY(ctx_ensure_arena(c, 8 * (np_max + 2) + 4096));
+    c->arena_reset();
+    unsigned long long *off = c->alloc<unsigned long long>(np_max + 2);
+    uint32_t *meta = c->d_mail + 640;            // [0] n, [1] pieces, [2] bad
+    if (!off) { set_error("arena exhausted"); return ARCHON_E_NOMEM; }
+    ARCHON_HIP_TRY(hipMemsetAsync(meta, 0, 3 * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(post::k_post_offsets, dim3(1), dim3(1024), 0, s, d_in, (unsigned long long)in_bytes, cap, off, meta, meta + 2);
+    hipLaunchKernelGGL(post::k_post_decode, dim3(div_up(np_max, post::kDecWaves)), dim3(64 * post::kDecWaves), 0, s, d_in, off, meta, d_bwt, meta + 2);
+    ARCHON_HIP_TRY(hipGetLastError());
+    ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 640, meta, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    c->launches += 2;
+    if (c->h_mail[642]) { set_error("post stage: malformed stream (flag 0x%x)", c->h_mail[642]); return ARCHON_E_CORRUPT; }
+    *n_out = c->h_mail[640];
+    return ARCHON_OK;
+}
+
+int archon_hip_post_decode_dev(const uint8_t *d_in, size_t in_bytes, uint8_t *d_bwt, uint32_t cap, uint32_t *n_out, int dev, void *stream)
+{
+    if (!d_in || !d_bwt || !n_out) { set_error("null pointer"); return ARCHON_E_ARG; }
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+    return post_decode_run(c, s, d_in, in_bytes, d_bwt, cap, n_out);
+}
+
+int archon_hip_inverse_post(const uint8_t *in, size_t in_bytes, uint32_t base_id, uint8_t *x_out, uint32_t cap, uint32_t *n_out, int dev)
+{
+    if (!in || !x_out || !n_out) { set_error("null pointer"); return ARCHON_E_ARG; }
+    if (cap > ARCHON_HIP_MAX_N) { set_error("block size %u out of range", cap); return ARCHON_E_ARG; }
+    Ctx *c;
+    ARCHON_TRY(ctx_get(dev, &c));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ARCHON_HIP_TRY(hipSetDevice(dev));
+    hipStream_t s = c->own_stream;
+    uint8_t *d_in = nullptr, *d_bwt = nullptr, *d_out = nullptr;
+    ARCHON_TRY(ctx_io(c, 0, in_bytes + 64, (void **)&d_in));
+    ARCHON_TRY(ctx_io(c, 1, (size_t)cap + 64, (void **)&d_bwt));
+    ARCHON_TRY(ctx_io(c, 2, (size_t)cap + 64, (void **)&d_out));
+    // only the packed stream crosses the link on the way in
+    ARCHON_HIP_TRY(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, s));
+    ARCHON_TRY(post_decode_run(c, s, d_in, in_bytes, d_bwt, cap, n_out));
+    const uint32_t n = *n_out;
+    if (n == 0) return ARCHON_OK;
+    if (base_id >= n) { set_error("base_id %u >= n %u", base_id, n); return ARCHON_E_ARG; }
+    ARCHON_TRY(keep_stats(c, inverse_run(c, s, d_bwt, n, base_id, d_out)));
+    ARCHON_HIP_TRY(hipMemcpyAsync(x_out, d_out, n, hipMemcpyDeviceToHost, s));
+    ARCHON_HIP_TRY(hipStreamSynchronize(s));
     return ARCHON_OK;
 }
 

@@ -198,6 +198,13 @@ int archon_hip_post_encode_dev(const uint8_t *d_bwt, uint32_t n, uint8_t *d_out,
  * cap may be below archon_hip_post_bound(n): a stream longer than cap makes the call fail with ARCHON_E_ARG (nothing is cut). */
 int archon_hip_forward_post(const uint8_t *x, uint32_t n, uint8_t *out, size_t cap, size_t *out_bytes, uint32_t *base_id, int dev);
 
+/* the way back (round 4): a block's stream on the device -> its BWT on the device (d_bwt holds cap bytes); *n_out = the block's length
+ * (host pointer; returned after a stream sync).  ARCHON_E_CORRUPT for a malformed stream. */
+int archon_hip_post_decode_dev(const uint8_t *d_in, size_t in_bytes, uint8_t *d_bwt, uint32_t cap, uint32_t *n_out, int dev, void *stream);
+/* host stream + primary index -> the block (x_out holds cap bytes), host buffers: stream decoded and BWT inverted on the device, only the
+ * packed stream goes up the link */
+int archon_hip_inverse_post(const uint8_t *in, size_t in_bytes, uint32_t base_id, uint8_t *x_out, uint32_t cap, uint32_t *n_out, int dev);
+
 /* ---- measurement ------------------------------------------------------------- */
 
 /* Per-stage device times (HIP events on the stream the kernels ran on) and
