@@ -246,13 +246,44 @@ int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out)
     if (bsize_out) *bsize_out = bsize;
     Pipe p;
     const int kWorkersPerGpu = workers_per_gpu(bsize);
-    if (!p.alloc((kWorkersPerGpu + 2) * ndev, (size_t)bsize + 4)) return ARCHON_E_NOMEM;
+    // 'RN' containers are decoded on the GPU when their pieces are the encoder's (32 KiB): the packed stream goes up the link, the
+    // stage is undone in front of the inverse transform (archon_hip_inverse_post).  Other piece sizes: host threads (post_unpack).
+    const bool gpu_post = post && kPiece == kPieceEnc;
+    const size_t in_cap = gpu_post ? post_slot_bytes(bsize) : (size_t)bsize + 4;       // (what the encoder's slots hold: it refuses longer streams)
+    if (!p.alloc((kWorkersPerGpu + 2) * ndev, in_cap, (size_t)bsize + 4)) return ARCHON_E_NOMEM;
 
     std::thread reader([&] {
         for (long b = 0;; ++b) {
             Slot *s;
             if (!p.wait(b, kFree, &s)) return;
-            if (post) {
+            if (post && gpu_post) {
+                // the packed stream as it is: the worker's GPU decodes it (csrc/post.hiph) in front of the inverse transform
+                uint32_t sz = 0;
+                if (fread(&sz, 4, 1, fi) != 1 || sz < 4 || sz > in_cap) { p.fail(-2); return; }
+                if (fread(s->in, 1, sz, fi) != sz || fread(&s->base, 4, 1, fi) != 1) { p.fail(-2); return; }
+                s->packed = sz;
+                uint32_t np = 0;
+                memcpy(&np, s->in, 4);
+                s->n = np ? 1 : 0;                 // (the block's length comes out of the decoder; an empty last block has no pieces)
+                s->last = false;
+                if (np == 0) { s->last = true; }
+                else {
+                    // a block is short -- the last one -- when its last piece is, or when it has fewer pieces than a whole block
+                    if ((size_t)np < ((size_t)bsize + kPiece - 1) / kPiece) s->last = true;
+                    else {
+                        size_t off = 4 + 4 * (size_t)np;
+                        bool ok = off <= sz;
+                        for (uint32_t k = 0; ok && k + 1 < np; ++k) { uint32_t ps; memcpy(&ps, s->in + 4 + 4 * k, 4); off += ps; ok = off + 4 <= sz; }
+                        if (!ok) { p.fail(-2); return; }
+                        uint32_t ln; memcpy(&ln, s->in + off, 4);
+                        s->last = (size_t)(np - 1) * kPiece + ln < bsize;
+                    }
+                }
+                const bool last = s->last;
+                p.set(s, kFilled);
+                if (last) { p.total(b + 1); return; }
+                continue;
+            } else if (post) {
                 uint32_t sz = 0;
                 if (fread(&sz, 4, 1, fi) != 1 || sz > 4 + ((size_t)bsize / kPiece + 1) * (4 + archon_post_bound(kPiece))) { p.fail(-2); return; }
                 std::vector<byte> packed(sz);
@@ -277,7 +308,13 @@ int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out)
     for (int w = 0; w < kWorkersPerGpu * ndev; ++w)
         workers.emplace_back([&, w] {
             archon_hip_bind_context(w % ndev, w / ndev);
-            worker_loop(p, w, kWorkersPerGpu * ndev, w % ndev, [](Slot &s, int dev) {
+            worker_loop(p, w, kWorkersPerGpu * ndev, w % ndev, [gpu_post, bsize](Slot &s, int dev) {
+                if (gpu_post) {
+                    uint32_t n = 0;
+                    const int rc = archon_hip_inverse_post(s.in, s.packed, s.base, s.out, bsize, &n, dev);
+                    s.n = n;
+                    return rc;
+                }
                 return archon_hip_inverse(s.in, (uint32_t)s.n, s.base, s.out, dev);
             });
         });

@@ -31,6 +31,7 @@ SYMBOLS = [
     "archon_hip_bind_context", "archon_hip_context_of_thread", "archon_hip_set_option", "archon_hip_get_option",
     "archon_hip_post_bound", "archon_hip_post_encode_dev", "archon_hip_forward_post", "archon_hip_validate_resident_dev",
     "archon_hip_forward_batch", "archon_hip_inverse_batch", "archon_hip_forward_batch_dev", "archon_hip_inverse_batch_dev",
+    "archon_hip_post_decode_dev", "archon_hip_inverse_post",
 ]
 
 
@@ -106,6 +107,8 @@ def load():
         "archon_hip_context_of_thread": [i32],
         "archon_hip_set_option": [i32, ctypes.c_char_p, ctypes.c_long],
         "archon_hip_get_option": [i32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_long)],
+        "archon_hip_post_decode_dev": [vp, sz, vp, u32, vp, i32, vp],
+        "archon_hip_inverse_post": [vp, sz, u32, vp, u32, vp, i32],
         "archon_hip_forward_batch": [vp, vp, u32, vp, vp, i32, i32],
         "archon_hip_inverse_batch": [vp, vp, vp, u32, vp, i32, i32],
         "archon_hip_forward_batch_dev": [vp, vp, u32, vp, vp, vp, i32, i32],
@@ -391,3 +394,21 @@ def inverse_batch_dev(bwt_ts, bases, out_ts, workers=0):
     ns = (ctypes.c_uint32 * len(bwt_ts))(*[t.numel() for t in bwt_ts])
     base = (ctypes.c_uint32 * len(bwt_ts))(*[int(v) for v in bases])
     _check(lib().archon_hip_inverse_batch_dev(_ptr_array([t.data_ptr() for t in bwt_ts]), ns, base, len(bwt_ts), _ptr_array([t.data_ptr() for t in out_ts]), dev, workers))
+
+
+def post_decode_dev(stream_t, nbytes, bwt_t):
+    """a block's stream of the post stage on the device -> its BWT on the device; returns the block's length"""
+    dev = stream_t.device.index or 0
+    n = ctypes.c_uint32(0)
+    _check(lib().archon_hip_post_decode_dev(ctypes.c_void_p(stream_t.data_ptr()), int(nbytes), ctypes.c_void_p(bwt_t.data_ptr()), bwt_t.numel(),
+                                            ctypes.cast(ctypes.byref(n), ctypes.c_void_p), dev, _stream_ptr()))
+    return int(n.value)
+
+
+def inverse_post(stream, base_id, cap, dev=0):
+    """host stream of the post stage + primary index -> the block (decoded and inverted on the device)"""
+    stream = np.ascontiguousarray(stream, dtype=np.uint8)
+    out = np.empty(cap, dtype=np.uint8)
+    n = ctypes.c_uint32(0)
+    _check(lib().archon_hip_inverse_post(_p(stream), stream.size, int(base_id), _p(out), cap, ctypes.cast(ctypes.byref(n), ctypes.c_void_p), dev))
+    return out[:n.value]

@@ -74,9 +74,80 @@ def _cases(oracle):
     return out
 
 
-@pytest.mark.parametrize("name", ["empty", "one", "one_zero", "run", "zeros_exact_piece", "zeros_piece_plus_1", "random", "bits", "all_symbols",
-                                  "all_symbols_rev", "chunk_edges", "runs_across_chunks", "fibonacci_counts", "bwt_text", "bwt_dna", "bwt_ab",
-                                  "bwt_motif", "bwt_prose"])
+_NAMES = ["empty", "one", "one_zero", "run", "zeros_exact_piece", "zeros_piece_plus_1", "random", "bits", "all_symbols",
+          "all_symbols_rev", "chunk_edges", "runs_across_chunks", "fibonacci_counts", "bwt_text", "bwt_dna", "bwt_ab",
+          "bwt_motif", "bwt_prose"]
+
+
+@pytest.mark.parametrize("name", _NAMES)
+def test_device_decoder_reads_host_stream(archon, oracle, host, name):
+    """the way back on the device (k_post_offsets, k_post_decode): the stream the HOST stage writes -- the statement of the
+    format -- decodes to the bytes it was made from; so does the device stage's own stream (equal by the test below)"""
+    import torch
+    data = np.ascontiguousarray(_cases(oracle)[name], np.uint8)
+    stream = np.frombuffer(host_stream(host, data), np.uint8)
+    d_in = torch.from_numpy(stream.copy()).cuda()
+    d_out = torch.full((data.size + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    n = archon.post_decode_dev(d_in, stream.size, d_out[:max(1, data.size)] if data.size else d_out[:1])
+    assert n == data.size
+    got = d_out.cpu().numpy()
+    assert (got[:n] == data).all()
+    assert (got[max(n, 1):] == 0xEE).all()                   # nothing written behind the block
+
+
+def test_device_decoder_rejects_malformed_streams(archon, oracle, host):
+    import torch
+    data = S.gen_text(100000)
+    good = np.frombuffer(host_stream(host, data), np.uint8).copy()
+    d_out = torch.empty(data.size, dtype=torch.uint8, device="cuda")
+
+    def run(buf, nbytes=None):
+        d_in = torch.from_numpy(np.ascontiguousarray(buf)).cuda()
+        return archon.post_decode_dev(d_in, buf.size if nbytes is None else nbytes, d_out)
+    assert run(good) == data.size
+    for what in ("truncated", "piece_count", "piece_size", "piece_length", "code_length", "bits"):
+        bad = good.copy()
+        nbytes = None
+        if what == "truncated":
+            nbytes = good.size - 1000
+        elif what == "piece_count":
+            bad[0:4] = np.frombuffer(struct.pack("<I", 1 << 20), np.uint8)
+        elif what == "piece_size":
+            bad[4:8] = np.frombuffer(struct.pack("<I", 3), np.uint8)
+        elif what == "piece_length":
+            off = 4 + 4 * struct.unpack_from("<I", good.tobytes(), 0)[0]
+            bad[off:off + 4] = np.frombuffer(struct.pack("<I", 12345), np.uint8)
+        elif what == "code_length":
+            off = 4 + 4 * struct.unpack_from("<I", good.tobytes(), 0)[0]
+            bad[off + 4 + 40] = 33
+        else:
+            off = 4 + 4 * struct.unpack_from("<I", good.tobytes(), 0)[0]
+            bad[off + 4 + 258: off + 4 + 258 + 2000] ^= 0x5A          # garbage bits: wrong length or an unknown code
+        with pytest.raises(archon.ArchonError):
+            run(bad, nbytes)
+    # a buffer too small for the block
+    small = torch.empty(1000, dtype=torch.uint8, device="cuda")
+    with pytest.raises(archon.ArchonError):
+        archon.post_decode_dev(torch.from_numpy(good).cuda(), good.size, small)
+
+
+def test_inverse_post_round_trip(archon, oracle):
+    """host block -> archon_hip_forward_post -> archon_hip_inverse_post: only packed streams cross the link, both ways"""
+    L = archon.lib()
+    L.archon_hip_post_bound.restype = ctypes.c_size_t
+    L.archon_hip_post_bound.argtypes = [ctypes.c_uint32]
+    for shape, n in (("text", 1 << 20), ("dna", 300001), ("random", 70000), ("a", 50000)):
+        x = S.gen_shape(shape, n)
+        cap = L.archon_hip_post_bound(n)
+        out = np.empty(cap, np.uint8)
+        got, base = ctypes.c_size_t(0), ctypes.c_uint32(0)
+        rc = L.archon_hip_forward_post(x.ctypes.data, n, out.ctypes.data, cap, ctypes.byref(got), ctypes.cast(ctypes.byref(base), ctypes.c_void_p), 0)
+        assert rc == 0, L.archon_hip_last_error()
+        back = archon.inverse_post(out[:got.value], base.value, n)
+        assert back.size == n and (back == x).all(), shape
+
+
+@pytest.mark.parametrize("name", _NAMES)
 def test_device_stream_equals_host_stream(archon, oracle, host, name):
     data = np.ascontiguousarray(_cases(oracle)[name], np.uint8)
     want = host_stream(host, data)
