@@ -132,6 +132,26 @@ int ctx_ensure_arena(Ctx *c, size_t bytes)
     return ARCHON_OK;
 }
 
+// the second tier grows like the first; growing it never touches the first (a forward call asks for it in mid-flight)
+static int ctx_ensure_arena2(Ctx *c, size_t bytes)
+{
+    if (bytes <= c->arena2_bytes) return ARCHON_OK;
+    ARCHON_HIP_TRY(hipDeviceSynchronize());
+    if (c->arena2) {
+        ARCHON_HIP_TRY(hipFree(c->arena2));
+        c->arena2 = nullptr;
+        c->arena2_bytes = 0;
+    }
+    const size_t want = bytes + (bytes >> 4) + (1u << 20);
+    if (hipMalloc((void **)&c->arena2, want) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("device arena allocation of %zu bytes (general stage) failed", want);
+        return ARCHON_E_NOMEM;
+    }
+    c->arena2_bytes = want;
+    return ARCHON_OK;
+}
+
 int ctx_io(Ctx *c, int slot, size_t bytes, void **out)
 {
     if (bytes > c->io_bytes[slot]) {
@@ -172,7 +192,8 @@ static uint32_t h16_parts(int dev) { return eff_pass_ranges(dev) > 256u ? (uint3
 // groups the B list / a mid directory can hold: a group of the B list is longer than the S list's limit or straddles a
 // tile of the sweep that made it (at most one per tile)
 static size_t mid_dir_cap(uint32_t n) { return (size_t)n / 512 + 64; }
-static size_t forward_arena_bytes(uint32_t n, int dev)
+// Tier 1: what every block needs (the first stage and its tables).  Tier 2: what only the general stage needs.
+static size_t forward_stage1_bytes(uint32_t n, int dev, bool own_sa)
 {
     const size_t N = n;
     size_t b = 0;
@@ -181,13 +202,7 @@ static size_t forward_arena_bytes(uint32_t n, int dev)
     add(N + 64);                    // packed key text y (compacted alphabets)
     add(8 * key_words(n)); add(8 * key_words(n));       // keyA keyB
     add(8 * key_words(n));          // valA | valB
-    add(4 * (N + 1));               // rank
-    add(4 * N);                     // brk: the run shortcut's break table, kept for the break-distance round
-    add(4 * N);                     // sa (when the caller wants none)
-    add(4 * N); add(4 * N);         // v / gstart, keep
-    for (int i = 0; i < 6; ++i) add(4 * N);   // upos, ug, uitem (double-buffered): the B list
-    add(4 * (N / 2 + 8));           // the pair list's {row, flag} words
-    add(4 * scan_temp_words(N));
+    if (own_sa) add(4 * N);         // sa (when the caller wants none)
     add(4 * rs::status_words(n));
     add(4 * 8 * 256); add(4 * 8 * 256);       // ghist, gstart
     add(4 * 65536);                           // hist16
@@ -197,14 +212,28 @@ static size_t forward_arena_bytes(uint32_t n, int dev)
     add(sizeof(uint4) * (size_t)bs::kMaxRanges * bs::kTrashWords);
     add(4 * (size_t)h16_parts(dev) * 32768u);        // partial two-byte counts, one table per workgroup of the count
     add(4 * 1024);                            // counts, starts, ticket, err, base, totals, TieCtl
+    return b + (1u << 16);
+}
+static size_t forward_stage2_bytes(uint32_t n)
+{
+    const size_t N = n;
+    size_t b = 0;
+    auto add = [&](size_t bytes) { b += (bytes + 255) & ~size_t(255); };
+    add(4 * (N + 1));               // rank
+    add(4 * N);                     // brk: the run shortcut's break table, kept for the break-distance round
+    add(4 * N); add(4 * N);         // v / gstart, keep
+    for (int i = 0; i < 6; ++i) add(4 * N);   // upos, ug, uitem (double-buffered): the B list
+    add(4 * (N / 2 + 8));           // the pair list's {row, flag} words
+    add(4 * scan_temp_words(N));
     add(8 * N + 64); add(8 * N + 64); add(8 * N + 64);      // the S lists of the refinement rounds (double-buffered) and the rank log
     add(4 * (rw::kMaxCoarse + rw::fine_buckets(n) + 64));
     add(4 * 4 * (mid_dir_cap(n) + 8));                          // directory of the B list: first entry, first row, place in the big list, number among the big groups
     for (int i = 0; i < 4; ++i) add(16 * (mid_dir_cap(n) + 8)); // directories of the two mid classes, double-buffered
     add(4 * fwd::kMcWords);
     add(4 * ((size_t)n / fwd::kBfTile + 8)); add(4 * ((size_t)n / fwd::kBfTile / 32 + 8));       // per tile of the B list: groups before it, "holds big entries"
-    return b + 4096;
+    return b + (1u << 16);
 }
+static size_t forward_arena_bytes(uint32_t n, int dev) { return forward_stage1_bytes(n, dev, true); }
 
 struct FwdBuf {
     uint8_t *xa;
@@ -278,7 +307,8 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         uint32_t p = p_hint;
         bool dominant = p_hint != 0;        // the driver's period probe already named the period (and the groups may be unordered)
         if (!dominant) {
-            uint32_t *tab = B.upos[1];                      // 2 * kGapSlots words; the second triple buffers are idle
+            uint32_t *tab = B.hist16;                       // 2 * kGapSlots words (32 KiB) of the two-byte count's table, idle by now (256 KiB whatever n is:
+                                                            // a list buffer of a small block is shorter than the table)
             ARCHON_HIP_TRY(hipMemsetAsync(tab, 0, 2 * fwd::kGapSlots * sizeof(uint32_t), s));
             hipLaunchKernelGGL(fwd::k_gap_sample, dim3(div_up(div_up(n, fwd::kGapStride), 256)), dim3(256), 0, s, sa, B.v, n, tab);
             ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, tab, 2 * fwd::kGapSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -719,7 +749,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
 static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n, uint32_t *d_sa_user,
                        uint8_t *d_bwt, uint32_t *d_base_out)
 {
-    ARCHON_TRY(ctx_ensure_arena(c, forward_arena_bytes(n, c->dev)));
+    ARCHON_TRY(ctx_ensure_arena(c, forward_stage1_bytes(n, c->dev, d_sa_user == nullptr)));
     c->arena_reset();
     c->launches = 0;
     archon_hip_stats &st = c->stats;
@@ -727,24 +757,14 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     st.n = n;
 
     FwdBuf B;
+    memset(&B, 0, sizeof B);
     B.xa = c->alloc<uint8_t>((size_t)n + 64);
     B.y = c->alloc<uint8_t>((size_t)n + 64);
     B.keyA = c->alloc<uint64_t>(key_words(n));
     B.keyB = c->alloc<uint64_t>(key_words(n));
     B.valA = reinterpret_cast<uint32_t *>(c->alloc<uint64_t>(key_words(n)));
     B.valB = B.valA ? B.valA + ((size_t)n + 16) : nullptr;
-    B.rank = c->alloc<uint32_t>((size_t)n + 1);
-    B.brk = c->alloc<uint32_t>(n);
-    B.sa_own = c->alloc<uint32_t>(n);
-    B.v = c->alloc<uint32_t>(n);
-    B.keep = c->alloc<uint32_t>(n);
-    for (int i = 0; i < 2; ++i) {
-        B.upos[i] = c->alloc<uint32_t>(n);
-        B.ug[i] = c->alloc<uint32_t>(n);
-        B.uitem[i] = c->alloc<uint32_t>(n);
-    }
-    B.pairw = c->alloc<uint32_t>((size_t)n / 2 + 8);
-    B.scan_tmp = c->alloc<uint32_t>(scan_temp_words(n));
+    B.sa_own = d_sa_user ? nullptr : c->alloc<uint32_t>(n);
     B.sc.d_status = c->alloc<uint32_t>(rs::status_words(n));
     B.sc.d_ghist = c->alloc<uint32_t>(8 * 256);
     B.sc.d_gstart = c->alloc<uint32_t>(8 * 256);
@@ -755,28 +775,49 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     B.trash = c->alloc<uint4>((size_t)bs::kMaxRanges * bs::kTrashWords);
     B.h16part = c->alloc<uint32_t>((size_t)h16_parts(c->dev) * 32768u);
     B.small = c->alloc<uint32_t>(1024);
-    B.slist[0] = c->alloc<uint2>((size_t)n + 8);
-    B.slist[1] = c->alloc<uint2>((size_t)n + 8);
-    B.rlog = c->alloc<uint2>((size_t)n + 8);
-    B.dst = reinterpret_cast<uint32_t *>(B.rlog);               // (scratch of the run shortcut / the scans before the rounds)
-    B.rwb.r1 = B.rwb.r2 = nullptr;
-    B.rwb.cnt1 = c->alloc<uint32_t>(rw::kMaxCoarse + rw::fine_buckets(n) + 64);
-    B.rwb.cnt2 = B.rwb.cnt1 ? B.rwb.cnt1 + rw::kMaxCoarse : nullptr;
-    B.gdir_off = c->alloc<uint32_t>(mid_dir_cap(n) + 8);
-    B.gdir_row = c->alloc<uint32_t>(mid_dir_cap(n) + 8);
-    B.gcls = c->alloc<uint32_t>(mid_dir_cap(n) + 8);
-    B.gbig = c->alloc<uint32_t>(mid_dir_cap(n) + 8);
-    for (int i = 0; i < 2; ++i) {
-        B.dirS[i] = c->alloc<uint4>(mid_dir_cap(n) + 8);
-        B.dirL[i] = c->alloc<uint4>(mid_dir_cap(n) + 8);
-    }
-    B.mc = c->alloc<uint32_t>(fwd::kMcWords);
-    B.tile_g0 = c->alloc<uint32_t>((size_t)n / fwd::kBfTile + 8);
-    B.tile_big = c->alloc<uint32_t>((size_t)n / fwd::kBfTile / 32 + 8);
-    if (!B.small || !B.rlog || !B.rwb.cnt1 || !B.mc || !B.tile_big) {
+    if (!B.small || (!d_sa_user && !B.sa_own)) {
         set_error("arena exhausted");
         return ARCHON_E_NOMEM;
     }
+    st.arena_bytes = c->arena_off;
+    // Tier 2, when the block first needs it (a periodic block's break table, the entry sweep of the general stage): rank table,
+    // lists, logs, directories -- 70 N that a block the streaming stage settles never touches.
+    auto general_buffers = [&]() -> int {
+        if (B.rank) return ARCHON_OK;
+        ARCHON_TRY(ctx_ensure_arena2(c, forward_stage2_bytes(n)));
+        B.rank = c->alloc2<uint32_t>((size_t)n + 1);
+        B.brk = c->alloc2<uint32_t>(n);
+        B.v = c->alloc2<uint32_t>(n);
+        B.keep = c->alloc2<uint32_t>(n);
+        for (int i = 0; i < 2; ++i) {
+            B.upos[i] = c->alloc2<uint32_t>(n);
+            B.ug[i] = c->alloc2<uint32_t>(n);
+            B.uitem[i] = c->alloc2<uint32_t>(n);
+        }
+        B.pairw = c->alloc2<uint32_t>((size_t)n / 2 + 8);
+        B.scan_tmp = c->alloc2<uint32_t>(scan_temp_words(n));
+        B.slist[0] = c->alloc2<uint2>((size_t)n + 8);
+        B.slist[1] = c->alloc2<uint2>((size_t)n + 8);
+        B.rlog = c->alloc2<uint2>((size_t)n + 8);
+        B.dst = reinterpret_cast<uint32_t *>(B.rlog);               // (scratch of the run shortcut / the scans before the rounds)
+        B.rwb.r1 = B.rwb.r2 = nullptr;
+        B.rwb.cnt1 = c->alloc2<uint32_t>(rw::kMaxCoarse + rw::fine_buckets(n) + 64);
+        B.rwb.cnt2 = B.rwb.cnt1 ? B.rwb.cnt1 + rw::kMaxCoarse : nullptr;
+        B.gdir_off = c->alloc2<uint32_t>(mid_dir_cap(n) + 8);
+        B.gdir_row = c->alloc2<uint32_t>(mid_dir_cap(n) + 8);
+        B.gcls = c->alloc2<uint32_t>(mid_dir_cap(n) + 8);
+        B.gbig = c->alloc2<uint32_t>(mid_dir_cap(n) + 8);
+        for (int i = 0; i < 2; ++i) {
+            B.dirS[i] = c->alloc2<uint4>(mid_dir_cap(n) + 8);
+            B.dirL[i] = c->alloc2<uint4>(mid_dir_cap(n) + 8);
+        }
+        B.mc = c->alloc2<uint32_t>(fwd::kMcWords);
+        B.tile_g0 = c->alloc2<uint32_t>((size_t)n / fwd::kBfTile + 8);
+        B.tile_big = c->alloc2<uint32_t>((size_t)n / fwd::kBfTile / 32 + 8);
+        if (!B.rank || !B.rlog || !B.rwb.cnt1 || !B.mc || !B.tile_big) { set_error("arena exhausted (general stage)"); return ARCHON_E_NOMEM; }
+        st.arena_bytes = c->arena_off + c->arena2_off;
+        return ARCHON_OK;
+    };
     uint32_t *small = B.small;
     uint32_t *d_counts = small, *d_starts = small + 256;
     B.sc.d_ticket = small + 601;
@@ -930,6 +971,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     };
     // entry of the general stage (k_first_groups): clean SA, group starts and the compacted working set in one sweep
     auto first_groups = [&](int mode, const uint64_t *keys, const uint32_t *items, uint32_t shift, bool write_ws) -> int {
+        ARCHON_TRY(general_buffers());
         unsigned long long *fg_status = reinterpret_cast<unsigned long long *>(B.sc.d_status);
         const uint32_t tiles = div_up(n, fwd::kFgTile);
         ARCHON_HIP_TRY(hipMemsetAsync(fg_status, 0, (size_t)tiles * sizeof(unsigned long long), s));
@@ -1043,6 +1085,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     bool brk_ready = false;
     uint32_t period_breaks = 0;
     if (period_hint && !route_off(kRtNoChains)) {
+        ARCHON_TRY(general_buffers());
         uint32_t *d_lastbrk = small + 606;
         ARCHON_HIP_TRY(hipMemsetAsync(d_lastbrk, 0, 2 * sizeof(uint32_t), s));          // [0] last real break, [1] how many
         hipLaunchKernelGGL(fwd::k_period_breaks, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, period_hint, B.brk, d_lastbrk);
@@ -1780,7 +1823,8 @@ int archon_hip_forward_post(const uint8_t *x, uint32_t n, uint8_t *out, size_t c
 
 static int lms_select_run(Ctx *c, hipStream_t s, const uint8_t *d_x, uint32_t n, uint32_t *d_count, uint32_t *d_items, uint32_t *n1_out)
 {
-    ARCHON_TRY(ctx_ensure_arena(c, forward_arena_bytes(n, c->dev)));
+    // three word arrays over the items, two (key, value) pair buffers over the LMS half, scan and status words
+    ARCHON_TRY(ctx_ensure_arena(c, (size_t)n * 26 + 4 * scan_temp_words(n) + 4 * rs::status_words(n) + (1u << 20)));
     c->arena_reset();
     c->launches = 0;
     uint32_t *v = c->alloc<uint32_t>(n), *flag = c->alloc<uint32_t>(n), *dst = c->alloc<uint32_t>(n);
@@ -1983,7 +2027,8 @@ int archon_hip_reserve(uint32_t n, int dev, size_t *bytes_or_null)
     const size_t inv = inverse_arena_bytes(n);
     if (inv > need) need = inv;
     ARCHON_TRY(ctx_ensure_arena(c, need));
-    if (bytes_or_null) *bytes_or_null = c->arena_bytes;
+    ARCHON_TRY(ctx_ensure_arena2(c, forward_stage2_bytes(n)));       // (reserving means: no allocation inside a later call, whatever the block)
+    if (bytes_or_null) *bytes_or_null = c->arena_bytes + c->arena2_bytes;
     return ARCHON_OK;
 }
 
@@ -1999,6 +2044,7 @@ int archon_hip_release(int dev)
             (void)hipSetDevice(dev);
             (void)hipDeviceSynchronize();
             if (c->arena) (void)hipFree(c->arena);
+            if (c->arena2) (void)hipFree(c->arena2);
             for (int i = 0; i < Ctx::kIo; ++i)
                 if (c->io[i]) (void)hipFree(c->io[i]);
             if (c->d_mail) (void)hipFree(c->d_mail);

@@ -50,7 +50,7 @@ class Stats(ctypes.Structure):
         ("alphabet_bits", ctypes.c_uint32), ("period", ctypes.c_uint32),
         ("chain_items", ctypes.c_uint32), ("text_rounds", ctypes.c_uint32), ("seg_big_items", ctypes.c_uint64),
         ("chain_pairs", ctypes.c_uint64), ("break_rounds", ctypes.c_uint32), ("break_settled", ctypes.c_uint32),
-        ("mid_items", ctypes.c_uint64),
+        ("mid_items", ctypes.c_uint64), ("arena_bytes", ctypes.c_uint64),
     ]
 
     def asdict(self):

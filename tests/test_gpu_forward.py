@@ -358,6 +358,25 @@ def test_small_blocks_product_route(archon, oracle, n):
             assert archon.stats()["path"] == 0, (shape, n)
 
 
+def test_workspace_follows_the_block(archon, oracle):
+    """the device workspace a forward call uses (archon_hip_stats.arena_bytes).  A block the streaming stage
+    settles stays inside the first tier -- 26.1 bytes per input byte + 145 MB of fixed tables and slack (26.7 N at 256 MiB);
+    a block that needs the general stage takes the second tier too; both give the oracle's bytes."""
+    n = 32 << 20
+    x = S.gen_random(n)
+    sa, bwt, base = archon.forward(x)
+    st = archon.stats()
+    assert st["path"] == 1 and st["doubling_rounds"] == 0
+    assert st["arena_bytes"] <= 27 * n + (160 << 20), st["arena_bytes"] / n          # 26.1 N + the fixed tables and the buffers' slack (145 MB)
+    assert archon.validate(x, sa)
+    y = S.gen_text(1 << 20)
+    P, B, b0 = oracle.forward(y)
+    sa, bwt, base = archon.forward(y)
+    st2 = archon.stats()
+    assert (sa == P).all() and (bwt == B).all() and base == b0
+    assert st2["arena_bytes"] > 60 * y.size
+
+
 def _word_soup(n, vocab, word_len, seed, skew=1.3, alphabet=12):
     """tokens drawn (Zipf-like) from a small vocabulary of fixed-length words over a small alphabet: after the first stage the
     tied groups are the (word, offset) classes -- thousands to tens of thousands of rows each -- and every doubling round
@@ -393,6 +412,30 @@ def test_mid_groups(archon, oracle, monkeypatch, n, vocab, wl):
         else:
             seen_mid += st["mid_items"]
     assert seen_mid > 0
+
+
+def test_mid_groups_at_the_class_limits(archon, oracle, monkeypatch):
+    """groups of EXACTLY 1024 / 1025 / 4096 / 4097 / 16384 / 16385 rows (and their neighbours): distinct 16-byte words that occur
+    exactly that often, in random order -- the rows of a word's offsets 7 .. 15 are tied in groups of the word's count after the
+    first stage, on the boundaries between the S list, the two mid classes (a full LDS image: the end mark of the group falls
+    behind the last bitmap word) and the global path"""
+    rng = np.random.default_rng(16384)
+    counts = [16384, 16385, 16383, 4096, 4097, 4095, 1025, 1024, 1023, 8192, 2048, 2, 3, 1, 40000]
+    words = rng.integers(0, 256, size=(len(counts), 16)).astype(np.uint8)
+    toks = np.repeat(np.arange(len(counts)), counts)
+    rng.shuffle(toks)
+    x = words[toks].reshape(-1).copy()
+    P, B, b0 = oracle.forward(x)
+    for env in ({}, {"ARCHON_FORCE_PATH": "0"}, {"ARCHON_NO_TEXT_ROUNDS": "1"}, {"ARCHON_FORCE_PATH": "0", "ARCHON_NO_TEXT_ROUNDS": "1", "ARCHON_NO_RANK_WRITER": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sa, bwt, base = archon.forward(x)
+        st = archon.stats()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert (sa == P).all(), (env, int(np.argmax(sa != P)))
+        assert (bwt == B).all() and base == b0, env
+    assert st["mid_items"] > 0 and st["seg_big_items"] > 0
 
 
 @pytest.mark.parametrize("sigma", [2, 3, 4, 5, 9, 16])
