@@ -415,12 +415,12 @@ def test_mid_groups(archon, oracle, monkeypatch, n, vocab, wl):
 
 
 def test_mid_groups_at_the_class_limits(archon, oracle, monkeypatch):
-    """groups of EXACTLY 1024 / 1025 / 4096 / 4097 / 16384 / 16385 rows (and their neighbours): distinct 16-byte words that occur
+    """groups of EXACTLY 512 / 513 / 4096 / 4097 / 16384 / 16385 rows (and their neighbours; 1024 / 1025: the S list's limit in round 3): distinct 16-byte words that occur
     exactly that often, in random order -- the rows of a word's offsets 7 .. 15 are tied in groups of the word's count after the
     first stage, on the boundaries between the S list, the two mid classes (a full LDS image: the end mark of the group falls
     behind the last bitmap word) and the global path"""
     rng = np.random.default_rng(16384)
-    counts = [16384, 16385, 16383, 4096, 4097, 4095, 1025, 1024, 1023, 8192, 2048, 2, 3, 1, 40000]
+    counts = [16384, 16385, 16383, 4096, 4097, 4095, 1025, 1024, 1023, 513, 512, 511, 8192, 2048, 2, 3, 1, 40000]
     words = rng.integers(0, 256, size=(len(counts), 16)).astype(np.uint8)
     toks = np.repeat(np.arange(len(counts)), counts)
     rng.shuffle(toks)
