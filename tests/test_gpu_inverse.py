@@ -47,6 +47,18 @@ def test_inverse_long_chain_route(archon, oracle, slab, monkeypatch):
         assert (archon.inverse(B, base) == x).all(), (shape, n)
 
 
+@pytest.mark.parametrize("rows", ["0", "1"])
+def test_inverse_walk_variants(archon, oracle, rows, monkeypatch):
+    """the walk writes its slabs by quads through LDS rows (k_walk_rows, the default) or lane by lane (k_walk_queue)"""
+    monkeypatch.setenv("ARCHON_INV_ROWS", rows)
+    for slab in ("0", "128"):
+        monkeypatch.setenv("ARCHON_INV_SLAB", slab)
+        for shape, n in (("random", 300001), ("text", (1 << 21) + 5), ("dna", 400000), ("a", 140000)):
+            x = S.gen_shape(shape, n)
+            _, B, base = oracle.forward(x)
+            assert (archon.inverse(B, base) == x).all(), (shape, n, slab)
+
+
 def test_inverse_unaligned_device_buffers(archon, oracle):
     """chain copies start at any byte offset; so may the caller's buffers"""
     import torch

@@ -1,6 +1,7 @@
 // Micro-benchmark: one LSB pass of rs::k_scatter over 2^28 random (u64 key, u32 item) pairs, and what it costs without
 // its parts: MODE 0 = the product kernel's body, 1 = ranks from LDS atomics instead of ballot matching (unstable: timing
-// only), 2 = no global stores.  Not part of the product.
+// only), 2 = no global stores, 3 = the tiles' prefixes read from a table (what the look-back costs: the table is the status array
+// a finished pass leaves behind), 4 = match masks through LDS (ds_or_b64; stable), 5 = 3 + 4.  Not part of the product.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -13,7 +14,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_scatter_m(const uint64_t *__restr
                                                     uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, uint32_t n,
                                                     int shift, const uint32_t *__restrict__ gstart /*[256]*/,
                                                     uint32_t *__restrict__ status /*[ntiles][256]*/,
-                                                    uint32_t *__restrict__ ticket, uint32_t *__restrict__ err)
+                                                    uint32_t *__restrict__ ticket, uint32_t *__restrict__ err, const uint32_t *__restrict__ ref)
 {
     __shared__ uint64_t s_stage[kTile];          // 64 KiB, keys then (as u32) items
     __shared__ uint32_t s_whist[kNW][256];       // per-wave digit counts -> exclusive wave offsets
@@ -23,6 +24,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_scatter_m(const uint64_t *__restr
     __shared__ uint32_t s_tile;
 
     for (int i = threadIdx.x; i < kNW * 256; i += kBlock) (&s_whist[0][0])[i] = 0;
+    if (MODE >= 4) for (int i = threadIdx.x; i < kNW * 256; i += kBlock) s_stage[i] = 0ull;      // the match cells live in the staging buffer (free until step 3)
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint32_t tile = s_tile;
@@ -54,7 +56,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_scatter_m(const uint64_t *__restr
         if (MODE == 1) {
             pos[r] = (uint16_t)atomicAdd(&wh[d], valid ? 1u : 0u);      // unstable, one LDS atomic per item
         } else {
-        const uint64_t m = match_digit8(d, valid);
+        uint64_t m;
+        if (MODE >= 4) {
+            unsigned long long *cell = reinterpret_cast<unsigned long long *>(&s_stage[w * 256 + d]);
+            if (valid) atomicOr(cell, 1ull << lane);
+            m = valid ? *cell : 0ull;
+            if (valid && mbcnt64(m) == 0) *cell = 0ull;
+        } else m = match_digit8(d, valid);
         const uint32_t rank = mbcnt64(m);
         const uint32_t prev = wh[d];
         pos[r] = (uint16_t)(prev + rank);
@@ -105,7 +113,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_scatter_m(const uint64_t *__restr
         const uint32_t d = threadIdx.x;
         uint32_t excl = 0;
         uint32_t *mine = status + (size_t)tile * 256 + d;
-        if (tile != 0) {
+        if ((MODE == 3 || MODE == 5) && tile != 0) {
+            excl = ref[(size_t)(tile - 1) * 256 + d] & kValMask;
+            st_agent(mine, kFlagPre | ((excl + total) & kValMask));
+        } else if (tile != 0) {
             // Look back kLook tiles at a time: the status words of the predecessors are requested together (one latency
             // per kLook tiles instead of one per tile -- with ~500 tiles in flight a tile walks back through dozens of
             // them) and consumed in order, up to the first one that carries an inclusive prefix or is not published yet.
@@ -171,7 +182,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_scatter_m(const uint64_t *__restr
 }}
 using namespace archon;
 template <int MODE>
-static void run(const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, uint32_t n, const uint32_t *gstart, uint32_t *status, uint32_t *ticket, uint32_t *err, const char *tag)
+static void run(const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, uint32_t n, const uint32_t *gstart, uint32_t *status, uint32_t *ticket, uint32_t *err, const char *tag, const uint32_t *ref = nullptr)
 {
     const uint32_t ntiles = (n + rs::kTile - 1) / rs::kTile;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -179,7 +190,7 @@ static void run(const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32
     for (int it = 0; it < 4; ++it) {
         hipMemset(status, 0, (size_t)ntiles * 256 * 4); hipMemset(ticket, 0, 4);
         hipEventRecord(a);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(rs::k_scatter_m<MODE>), dim3(ntiles), dim3(rs::kBlock), 0, 0, kin, vin, kout, vout, n, 8, gstart, status, ticket, err);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rs::k_scatter_m<MODE>), dim3(ntiles), dim3(rs::kBlock), 0, 0, kin, vin, kout, vout, n, 8, gstart, status, ticket, err, ref);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         if (it && ms < best) best = ms;
@@ -201,5 +212,19 @@ int main()
     run<0>(kin, vin, kout, vout, n, gstart, status, ticket, ticket + 1, "k_scatter as shipped");
     run<1>(kin, vin, kout, vout, n, gstart, status, ticket, ticket + 1, "ranks by LDS atomics (unstable)");
     run<2>(kin, vin, kout, vout, n, gstart, status, ticket, ticket + 1, "no global stores");
+    const uint32_t ntiles = (n + rs::kTile - 1) / rs::kTile;
+    uint32_t *ref; hipMalloc(&ref, (size_t)ntiles * 1024);
+    run<0>(kin, vin, kout, vout, n, gstart, status, ticket, ticket + 1, "k_scatter as shipped (again)");
+    hipMemcpy(ref, status, (size_t)ntiles * 1024, hipMemcpyDeviceToDevice);
+    uint64_t *kref; hipMalloc(&kref, (size_t)n * 8); hipMemcpy(kref, kout, (size_t)n * 8, hipMemcpyDeviceToDevice);
+    run<3>(kin, vin, kout, vout, n, gstart, status, ticket, ticket + 1, "tile prefixes from a table (no look-back)", ref);
+    run<4>(kin, vin, kout, vout, n, gstart, status, ticket, ticket + 1, "match masks through LDS", ref);
+    {
+        uint64_t *a = (uint64_t *)malloc((size_t)n * 8);
+        hipMemcpy(a, kout, (size_t)n * 8, hipMemcpyDeviceToHost); hipMemcpy(h, kref, (size_t)n * 8, hipMemcpyDeviceToHost);
+        size_t bad = 0; for (uint32_t i = 0; i < n; ++i) bad += a[i] != h[i];
+        printf("  LDS masks against ballots: %zu keys differ\n", bad);
+    }
+    run<5>(kin, vin, kout, vout, n, gstart, status, ticket, ticket + 1, "both", ref);
     return 0;
 }
