@@ -2106,7 +2106,7 @@ int archon_hip_test_route(const char *name, long value)
         return ARCHON_OK;
     }
     if (!strcmp(name, "SMALL_BLOCK")) { g_route.small_block = value; return ARCHON_OK; }
-    if (!strcmp(name, "INV_ROWS")) { g_route.inv_rows = value < 0 ? -1 : value ? 1 : 0; return ARCHON_OK; }
+    if (!strcmp(name, "INV_ROWS")) { g_route.inv_rows = value < 0 ? -1 : value > 2 ? 1 : (int)value; return ARCHON_OK; }
     if (!strcmp(name, "INV_SLAB")) { g_route.inv_slab = value > 0 ? (uint32_t)value : 0u; return ARCHON_OK; }
     if (!strcmp(name, "INV_SBITS")) { g_route.inv_sbits = (int)value; return ARCHON_OK; }
     if (!strcmp(name, "INV_WALK_WGS")) { g_route.inv_walk_wgs = (int)value; return ARCHON_OK; }
