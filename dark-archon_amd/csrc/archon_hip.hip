@@ -996,6 +996,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // the chip -- its two-byte count keeps 128 KiB of counters per workgroup on all 256 CUs, its bucket sort launches 65 536
     // workgroups -- and costs 0.7 ms whatever the block holds.  Below kSmallBlock a block takes a plain byte count and the LSB
     // passes, whose cost follows its size.
+    bool tail_fetched = false, period_probed = false;
     const uint32_t small_limit = g_route.small_block >= 0 ? (uint32_t)g_route.small_block : kSmallBlock;
     const bool small_block = forced < 0 && n >= 8 && n < small_limit;
     if (small_block) {
@@ -1004,6 +1005,20 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         e1 = tm.mark();
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 128, d_counts, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 512, d_x + (n - 1), 1, hipMemcpyDeviceToHost, s));
+        // (a small block's time is its host round trips: the period probe and the block's last bytes -- what the LSB passes' digit
+        //  counts need -- travel with the byte count instead of taking one each further down)
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 520, d_x + (n - 8), 8, hipMemcpyDeviceToHost, s));
+        tail_fetched = true;
+        if (n >= (1u << 16) && !route_off(kRtNoPeriodProbe)) {
+            uint32_t *pres = small + 610;
+            c->h_mail[528] = 0xFFFFFFFFu; c->h_mail[529] = 0;
+            ARCHON_HIP_TRY(hipMemcpyAsync(pres, c->h_mail + 528, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(fwd::k_period_find, dim3(fwd::kPeriodSearch / 256), dim3(256), 0, s, d_x, n, pres);
+            hipLaunchKernelGGL(fwd::k_period_vote, dim3(fwd::kPeriodVotes / 256), dim3(256), 0, s, d_x, n, pres);
+            ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 530, pres, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            c->launches += 2;
+            period_probed = true;
+        }
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         // (in the form the two-byte count leaves its column sums in -- the bytes x[0 .. n-2] and the 0xFF in front of x[0] --
         //  which is what the code below undoes)
@@ -1053,13 +1068,17 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     uint32_t key_bytes = fwd::kKeyBytes, period_hint = 0;
     if (path == 0 && n >= (1u << 16) && !route_off(kRtNoPeriodProbe)) {
         uint32_t *pres = small + 610;
-        c->h_mail[0] = 0xFFFFFFFFu; c->h_mail[1] = 0;
-        ARCHON_HIP_TRY(hipMemcpyAsync(pres, c->h_mail, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(fwd::k_period_find, dim3(fwd::kPeriodSearch / 256), dim3(256), 0, s, d_x, n, pres);
-        hipLaunchKernelGGL(fwd::k_period_vote, dim3(fwd::kPeriodVotes / 256), dim3(256), 0, s, d_x, n, pres);
-        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, pres, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
-        c->launches += 2;
+        if (period_probed) {                         // (a small block: the probe went out with the byte count)
+            c->h_mail[0] = c->h_mail[530]; c->h_mail[1] = c->h_mail[531];
+        } else {
+            c->h_mail[0] = 0xFFFFFFFFu; c->h_mail[1] = 0;
+            ARCHON_HIP_TRY(hipMemcpyAsync(pres, c->h_mail, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(fwd::k_period_find, dim3(fwd::kPeriodSearch / 256), dim3(256), 0, s, d_x, n, pres);
+            hipLaunchKernelGGL(fwd::k_period_vote, dim3(fwd::kPeriodVotes / 256), dim3(256), 0, s, d_x, n, pres);
+            ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, pres, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            ARCHON_HIP_TRY(hipStreamSynchronize(s));
+            c->launches += 2;
+        }
         if (c->h_mail[0] != 0xFFFFFFFFu && c->h_mail[1] * 10 >= fwd::kPeriodVotes * 9) {
             key_bytes = 3;
             // ... provided every two-byte bucket is ONE run of the period: a bucket that joins two phases of the period (the same
@@ -1176,8 +1195,10 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
                 uint32_t H[256];
                 const uint32_t last_byte = c->h_mail[512] & 0xFFu;
                 for (uint32_t v = 0; v < 256; ++v) H[v] = c->h_mail[128 + v] - (v == 0xFFu ? 1u : 0u) + (v == last_byte ? 1u : 0u);
-                ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 520, d_x + (n - 8), 8, hipMemcpyDeviceToHost, s));
-                ARCHON_HIP_TRY(hipStreamSynchronize(s));
+                if (!tail_fetched) {
+                    ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 520, d_x + (n - 8), 8, hipMemcpyDeviceToHost, s));
+                    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+                }
                 const uint8_t *tail = reinterpret_cast<const uint8_t *>(c->h_mail + 520);      // x[n-8 .. n-1]
                 for (uint32_t q = 1; q <= 7; ++q) {
                     uint32_t *hq = hist_given + (8 - q) * 256;                               // pass p = 8 - q sorts on key byte q
