@@ -13,7 +13,7 @@
  *   SMALL_BLOCK  bytes / -1   blocks below this size take the byte count + LSB passes instead of the streaming stage (-1: 8 MiB)
  *   INV_SLAB, INV_SBITS, INV_WALK_WGS   inverse: slab bytes per chain, log2 rows per chain head, walk workgroups per CU
  *   NO_ALIGNED NO_BREAK_ROUND NO_CHAINS NO_DEEP_HINT NO_PACK NO_PACK_STREAM NO_PAIR_CHAINS NO_PERIOD_HINT NO_PERIOD_PROBE
- *   NO_PERIOD_STREAM NO_PROBE NO_RANK_WRITER NO_TEXT_ROUNDS NO_MID      nonzero switches the named step off
+ *   NO_PERIOD_STREAM NO_PROBE NO_RANK_WRITER NO_TEXT_ROUNDS NO_MID NO_SHALLOW      nonzero switches the named step off
  * Returns 0, or ARCHON_E_ARG for an unknown name / a value out of range.  Process-wide; not thread-safe against
  * concurrent transforms (tests run one at a time).
  */

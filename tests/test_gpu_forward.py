@@ -358,6 +358,29 @@ def test_small_blocks_product_route(archon, oracle, n):
             assert archon.stats()["path"] == 0, (shape, n)
 
 
+@pytest.mark.small_block_default
+@pytest.mark.parametrize("no_shallow", ["0", "1"])
+def test_key_depth_follows_the_byte_counts(archon, oracle, no_shallow, monkeypatch):
+    """a block whose byte counts promise hardly any tie at fewer than seven key bytes (incompressible data) sorts on fewer:
+    3 or 4 LSB passes instead of 7, whatever stays tied goes to the rounds; text keeps seven; NO_SHALLOW switches it off"""
+    monkeypatch.setenv("ARCHON_NO_SHALLOW", no_shallow)
+    for shape, n, passes in (("random", 1 << 16, 3), ("random", (1 << 20) + 1, 4), ("random", 4 << 20, 4), ("random_copy", 3 << 20, 4),
+                             ("text", 1 << 20, 7), ("prose", 1 << 20, 7), ("dna", 1 << 20, None)):
+        x = S.gen_shape(shape, n)
+        P, B, b0 = oracle.forward(x)
+        sa, bwt, base = archon.forward(x)
+        assert (sa == P).all() and (bwt == B).all() and base == b0, (shape, n)
+        st = archon.stats()
+        if passes is not None:
+            assert st["radix_passes"] == (7 if no_shallow == "1" else passes), (shape, n, st["radix_passes"])
+    # ties that the short keys leave: a random block with a copied region is tied deep whatever the counts say
+    x = S.gen_random(2 << 20)
+    x[(1 << 20):(1 << 20) + 300000] = x[1000:301000]
+    P, B, b0 = oracle.forward(x)
+    sa, bwt, base = archon.forward(x)
+    assert (sa == P).all() and (bwt == B).all() and base == b0
+
+
 def test_workspace_follows_the_block(archon, oracle):
     """the device workspace a forward call uses (archon_hip_stats.arena_bytes).  A block the streaming stage
     settles stays inside the first tier -- 26.1 bytes per input byte + 145 MB of fixed tables and slack (26.7 N at 256 MiB);
