@@ -30,7 +30,7 @@ for sh in random dna text a ab motif prose motif_defects random_copy; do
   timeout -k 10 120 python3 tools/stage_times.py 256 $sh 3 2>/dev/null | tail -1 | sed "s/^/$sh /" >> $out/stage_times.txt || exit 1
 done
 timeout -k 10 120 python3 tools/stage_times.py 256 random 3 inv 2>/dev/null | tail -1 | sed "s/^/inverse-random /" >> $out/stage_times.txt
-for mib in 4 16 64; do
+for mib in 4 16 64 128; do
   timeout -k 10 120 python3 tools/stage_times.py $mib random 3 2>/dev/null | tail -1 | sed "s/^/forward-random-${mib}MiB /" >> $out/stage_times.txt
   timeout -k 10 120 python3 tools/stage_times.py $mib random 3 inv 2>/dev/null | tail -1 | sed "s/^/inverse-random-${mib}MiB /" >> $out/stage_times.txt
 done
@@ -60,8 +60,10 @@ timeout -k 10 300 python3 tools/inv_sbits_sweep.py 2>/dev/null > $out/inv_sbits_
 timeout -k 10 300 python3 tools/validate_timing.py 256 2>/dev/null | tail -1 > $out/validate_timing.json; cat $out/validate_timing.json
 timeout -k 10 300 python3 tools/post_bench.py 256 > $out/post_stage.txt 2>/dev/null
 hipcc -O3 --offload-arch=gfx950 -o /tmp/gather_chain tools/micro/gather_chain.hip 2>/dev/null && timeout -k 10 300 /tmp/gather_chain > $out/micro_gather_chain.txt 2>&1
-timeout -k 10 200 python3 tools/inv_exp.py 2>/dev/null | tail -4 > $out/inverse_walk_parts.txt
-for m in lds_rates pass_model scatter_pass; do
+timeout -k 10 200 python3 tools/inv_exp.py 2>/dev/null | tail -5 > $out/inverse_walk_parts.txt
+bash tools/inv_kernels.sh 8 > $out/inverse_kernels.txt 2>&1
+timeout -k 10 300 python3 tools/post_decode_bench.py 256 > $out/post_decode.txt 2>/dev/null
+for m in lds_rates pass_model scatter_pass lf_build; do
   hipcc -O3 --offload-arch=gfx950 -o /tmp/$m tools/micro/$m.hip 2>/dev/null && timeout -k 10 120 /tmp/$m > $out/micro_$m.txt 2>&1
 done
 fi

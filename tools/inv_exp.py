@@ -10,7 +10,7 @@ x = torch.from_numpy(S.gen_shape("random", n)).cuda()
 sa = torch.empty(n, dtype=torch.int32, device="cuda"); bwt = torch.empty(n, dtype=torch.uint8, device="cuda"); base = torch.zeros(1, dtype=torch.int32, device="cuda")
 pyarchon.forward_dev(x, sa, bwt, base)
 out = torch.empty(n, dtype=torch.uint8, device="cuda")
-for flags in ("0", "32", "0", "32"):
+for flags in ("0", "1", "2", "4", "8"):
     os.environ["ARCHON_EXP_WALK"] = flags
     for r in range(2):
         try:
