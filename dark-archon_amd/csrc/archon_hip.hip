@@ -1036,6 +1036,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         path = (forced == 1 || (uint64_t)big_items * 2 <= n) ? 1 : 0;
     }
     }
+    constexpr uint32_t kPackSigma = 32;          // alphabets up to this many distinct bytes sort on packed keys
     uint32_t sigma = 0, bits = 8;
     uint8_t *d_lut = reinterpret_cast<uint8_t *>(small + 900);
     uint8_t h_lut[256];
@@ -1129,10 +1130,12 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         }
         bits = 1;
         while ((1u << bits) < sigma) ++bits;
-        if (sigma <= 16 && !route_off(kRtNoPack)) {
+        // (17 ... 32 distinct bytes -- lower-case prose -- still pack: five bits per symbol, eleven symbols in the seven key bytes instead of
+        //  seven; the streaming stage's key text holds whole symbols per byte and stops at 16)
+        if (sigma <= kPackSigma && !route_off(kRtNoPack)) {
             memcpy(c->h_mail + 1024, h_lut, 256);
             ARCHON_HIP_TRY(hipMemcpyAsync(d_lut, c->h_mail + 1024, 256, hipMemcpyHostToDevice, s));
-            if (sigma >= 2 && forced < 0 && !small_block && !route_off(kRtNoPackStream)) {
+            if (sigma >= 2 && sigma <= 16 && forced < 0 && !small_block && !route_off(kRtNoPackStream)) {
                 const int q = bits == 1 ? 8 : bits == 2 ? 4 : 2;
                 const dim3 grid(div_up(div_up(n, 16), 256)), block(256);
                 if (q == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_build_y<8>), grid, block, 0, s, d_x, n, d_lut, B.y);
@@ -1177,7 +1180,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     } else {
         // ---- first stage for heavily skewed blocks: LSB passes on packed 7-byte keys ----
         // alphabet compaction: with <= 16 distinct bytes the key holds 56/bits symbols
-        const bool packed = sigma <= 16 && !route_off(kRtNoPack);
+        const bool packed = sigma <= kPackSigma && !route_off(kRtNoPack);
         static thread_local uint32_t hist_given[8 * 256];
         bool use_given = false, shallow = false;
         if (packed) {

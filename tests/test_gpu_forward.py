@@ -170,13 +170,17 @@ def test_large_shapes_lf_consistent(archon, shape):
 
 
 def test_alphabet_compaction(archon, oracle):
-    """SURVEY 8(f) N2: with <= 16 distinct bytes the 7-pass route packs 56/bits symbols per key;
-    packed and byte keys must give the same SA (and the oracle's), also at the 16/17-symbol edge."""
+    """with <= 32 distinct bytes the 7-pass route packs 56/bits symbols per key (17 ... 32 symbols: five bits,
+    eleven symbols -- the key's last bit stays empty); packed and byte keys must give the same SA (and the oracle's), also at
+    the 16/17- and the 32/33-symbol edges."""
     import os
     rng = np.random.default_rng(11)
     cases = [S.gen_dna(200000), S.gen_repeat(70001, b"ab"), S.gen_repeat(5000, b"a"),
              rng.choice(np.arange(100, 116, dtype=np.uint8), size=150000),          # 16 symbols -> 4 bits
-             rng.choice(np.arange(100, 117, dtype=np.uint8), size=150000),          # 17 symbols -> bytes
+             rng.choice(np.arange(100, 117, dtype=np.uint8), size=150000),          # 17 symbols -> 5 bits
+             rng.choice(np.arange(200, 232, dtype=np.uint8), size=150000),          # 32 symbols -> 5 bits, code 31 = the pad code
+             rng.choice(np.arange(223, 256, dtype=np.uint8), size=150000),          # 33 symbols -> bytes (0xFF present)
+             S.gen_shape("prose", 300000),                                          # 28 symbols, deep ties
              rng.choice(np.array([0, 255], np.uint8), size=100000),                 # codes 0/1 with 0xFF present
              rng.choice(np.array([7, 9, 200], np.uint8), size=90000, p=[0.9, 0.05, 0.05])]
     for x in cases:
@@ -191,7 +195,8 @@ def test_alphabet_compaction(archon, oracle):
             os.environ.pop("ARCHON_NO_PACK", None)
             os.environ.pop("ARCHON_FORCE_PATH", None)
         nsym = len(np.unique(x))
-        assert (bits > 0) == (nsym <= 16), (nsym, bits)
+        assert (bits > 0) == (nsym <= 32), (nsym, bits)
+        if bits: assert bits == max(1, int(np.ceil(np.log2(nsym)))), (nsym, bits)
         P, B, b0 = oracle.forward(x)
         assert (sa1 == P).all() and (sa2 == P).all() and (bwt1 == B).all() and b1 == b0 == b2
 
