@@ -1185,8 +1185,12 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         bool use_given = false, shallow = false;
         if (packed) {
             h0 = 56 / bits;
-            hipLaunchKernelGGL(fwd::k_init_keys_packed, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, d_lut, bits, h0,
-                               B.keyA, B.valA);
+            ARCHON_HIP_TRY(hipMemsetAsync(B.sc.d_ghist, 0, 8 * 256 * sizeof(uint32_t), s));
+            {
+                const uint32_t want = div_up(div_up(n, 4), 256), cap = (uint32_t)kNumCU * 8;
+                hipLaunchKernelGGL(fwd::k_init_keys_packed, dim3(want < cap ? want : cap), dim3(256), 0, s, d_x, n, d_lut, bits, h0,
+                                   B.keyA, B.valA, B.sc.d_ghist);        // (... and the digit counts of the passes)
+            }
             st.alphabet_bits = bits;
             h0 = (8 * key_bytes) / bits;            // symbols the sorted key bytes hold
         } else {
@@ -1236,7 +1240,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         if (!packed && !from_text)
             hipLaunchKernelGGL(fwd::k_init_keys, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, B.keyA, B.valA);
         ARCHON_TRY(rs::sort_pairs(s, B.sc, B.keyA, B.valA, B.keyB, B.valB, n, pass_mask, &in_b, &st.radix_passes, &c->launches, &pt,
-                                  use_given ? hist_given : nullptr, from_text ? d_x : nullptr));
+                                  use_given ? hist_given : nullptr, from_text ? d_x : nullptr, packed));
         if (from_text && st.radix_passes == 0)          // every digit constant: no pass ran, the pairs still have to exist
             hipLaunchKernelGGL(fwd::k_init_keys, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, B.keyA, B.valA);
         uint64_t *kS = in_b ? B.keyB : B.keyA;
