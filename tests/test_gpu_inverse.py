@@ -47,11 +47,12 @@ def test_inverse_long_chain_route(archon, oracle, slab, monkeypatch):
         assert (archon.inverse(B, base) == x).all(), (shape, n)
 
 
-@pytest.mark.parametrize("rows", ["0", "1"])
+@pytest.mark.parametrize("rows", ["0", "1", "2"])
 def test_inverse_walk_variants(archon, oracle, rows, monkeypatch):
-    """the walk writes its slabs by quads through LDS rows (k_walk_rows, the default) or lane by lane (k_walk_queue)"""
+    """the walk writes its slabs by quads through LDS rows (k_walk_rows: 128-byte rows = 1, the product's choice above 128 MiB; 64-byte rows = 2)
+    or lane by lane (k_walk_queue = 0)"""
     monkeypatch.setenv("ARCHON_INV_ROWS", rows)
-    for slab in ("0", "128"):
+    for slab in ("0", "128", "192"):          # (192: a multiple of 64 only -- the 128-byte rows fall back to 64-byte ones)
         monkeypatch.setenv("ARCHON_INV_SLAB", slab)
         for shape, n in (("random", 300001), ("text", (1 << 21) + 5), ("dna", 400000), ("a", 140000)):
             x = S.gen_shape(shape, n)
