@@ -46,24 +46,34 @@ B_FIRST_PASS = 5.0             # first LSB pass (read 1 key byte
 B_LOCAL_SORT = 13.0            # in-LDS bucket sort: read one 8-byte record, write SA 4 + BWT 1
 
 
-def cpu_baseline(block_bytes):
-    """Single-thread CPU figure on a bounded sample (about 10-30 s of CPU work)."""
+def cpu_baseline(block_bytes, sample_mib):
+    """Single-thread CPU figure: the reference a7 on the WHOLE block of the metric (the block, one
+    core, taskset-pinned, clock() around compute as bwt/a7/src/main.cpp:39-41 does), one stated run -- about a minute on
+    a 256 MiB block; --cpu-sample-mib bounds it to the first so many MiB."""
     import archon_synth
     ref = os.path.join(ROOT, "oracle", "_ref", "a7ref")
-    sample_n = min(block_bytes, 64 << 20)
+    sample_n = min(block_bytes, sample_mib << 20)
     x = archon_synth.gen_random(sample_n)
-    sample = "first %d MiB of the rank-0 block (uniform random bytes), SA+BWT, clock() around compute" % (sample_n >> 20)
+    whole = sample_n == block_bytes
+    sample = ("the whole rank-0 block (%d MiB of uniform random bytes)" if whole else "first %d MiB of the rank-0 block (uniform random bytes)") % (sample_n >> 20)
+    sample += ", SA+BWT, clock() around compute, one run"
+    # one core of those this process may use (the last one: away from the cores the runtime's helper threads favour)
+    try:
+        core = sorted(os.sched_getaffinity(0))[-1]
+    except Exception:
+        core = None
+    pin = ["taskset", "-c", str(core)] if core is not None and os.path.exists("/usr/bin/taskset") else []
     if os.path.exists(ref):
         tag = "/tmp/bench_a7ref_%d" % os.getpid()
         x.tofile(tag + ".in")
         try:
-            r = subprocess.run([ref, "e", tag + ".in", tag + ".bwt"], capture_output=True, text=True, timeout=600)
+            r = subprocess.run(pin + [ref, "e", tag + ".in", tag + ".bwt"], capture_output=True, text=True, timeout=900)
             kv = dict(t.split("=") for t in r.stdout.split())
             if r.returncode == 0 and int(kv.get("validate", "0")) == 1:
                 secs = float(kv["sa_time"])
                 out = {"value": round(sample_n / 1e6 / secs, 3), "unit": "MB/s", "cores": 1, "kind": "reference",
-                       "sample": sample + "; reference a7 -O3 (oracle/_ref/a7ref)",
-                       "host_cores": os.cpu_count()}
+                       "sample": sample + "; reference a7 -O3 (oracle/_ref/a7ref)", "seconds": round(secs, 2),
+                       "pinned": bool(pin), "core": core, "runs": 1, "host_cores": os.cpu_count()}
                 return out
         except Exception:
             pass
@@ -75,14 +85,19 @@ def cpu_baseline(block_bytes):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding
     orc = oracle_binding.Oracle()
-    sample_n = min(sample_n, 32 << 20)
+    if pin:
+        try:
+            os.sched_setaffinity(0, {core})
+        except Exception:
+            pin = []
+    sample_n = min(sample_n, 64 << 20)
     x = x[:sample_n]
     t0 = orc.L.oracle_clock_seconds()
     orc.forward(x)
     secs = orc.L.oracle_clock_seconds() - t0
     return {"value": round(sample_n / 1e6 / secs, 3), "unit": "MB/s", "cores": 1, "kind": "port",
-            "sample": "first %d MiB of the rank-0 block; oracle/archon_oracle.c" % (sample_n >> 20),
-            "host_cores": os.cpu_count()}
+            "sample": "first %d MiB of the rank-0 block; oracle/archon_oracle.c, one run" % (sample_n >> 20), "seconds": round(secs, 2),
+            "pinned": bool(pin), "core": core, "runs": 1, "host_cores": os.cpu_count()}
 
 
 def reference_digest(shape, block, n):
@@ -109,17 +124,84 @@ def sha256_of(*parts):
 
 
 def pmc_traffic(path, n, shape, kname):
-    """HBM bytes per launch of the dominant kernel, from the committed PMC summary (same command,
-    separate --pmc passes, gfx950 FETCH_SIZE correction applied as documented there)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            t = json.load(f)
-        key = "path%d_%s_%d" % (path, shape, n)
-        short = kname.split(" ")[0]
-        ent = t.get(key, {}).get(short)
-        return ent["hbm_bytes_per_launch"] if ent else None
-    except Exception:
-        return None
+    """HBM bytes per launch of the dominant kernel, from the committed PMC summary of the newest round that holds one
+    (profiles/rNN_final/pmc_traffic.json: same command, separate --pmc passes, gfx950 FETCH_SIZE correction applied as
+    documented there), with the file it came from."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_final", "pmc_traffic.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                t = json.load(fh)
+            ent = t.get("path%d_%s_%d" % (path, shape, n), {}).get(kname.split(" ")[0])
+            if ent:
+                return ent["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
+PATH_NAMES = {0: "7 LSB passes on packed keys + refinement rounds", 1: "streaming (hist16, 2 LSB passes, in-LDS bucket sort)",
+              2: "closed form of a clean periodic block (sort of its first 2p bytes, expanded)"}
+EXTRA_SHAPES = ("dna", "a", "ab", "motif", "text", "prose")
+
+
+def extra_shapes(n, dev, names):
+    """The other named shapes of BASELINE.json (configs[2..4]) at the block size of the metric, AFTER the timed region of the
+    graded config: one warm-up + best of 3 per shape, each gated by the reference's own digests (golden_full.json)."""
+    import torch
+    import archon_synth
+    import pyarchon
+    out = {}
+    x_t = torch.empty(n, dtype=torch.uint8, device=dev)
+    sa_t = torch.empty(n, dtype=torch.int32, device=dev)
+    o_t = torch.empty(n + 4, dtype=torch.uint8, device=dev)
+    ok = True
+    for name in names:
+        x_t.copy_(torch.from_numpy(archon_synth.gen_shape(name, n)))
+        best, best_dev, st = None, None, None
+        for r in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pyarchon.forward_dev(x_t, sa_t, o_t[:n], o_t[n:].view(torch.int32))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            st = pyarchon.stats(dev.index or 0)
+            if r and (best is None or dt < best):
+                best, best_dev = dt, st["ms_total"]
+        ref = reference_digest(name, 0, n)
+        sha = None
+        if ref is not None:
+            sha = sha256_of(o_t.cpu().numpy()) == ref["sha256_bwt_base"] and sha256_of(sa_t.cpu().numpy()) == ref["sha256_P"]
+            ok = ok and sha
+        out[name] = {"ms": round(best * 1e3, 3), "device_ms": round(best_dev, 3), "MB_s": round(n / 1e6 / best, 1),
+                     "frac_57B_model": round(B_FWD_CFG2 * n / (best_dev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "path": PATH_NAMES.get(st["path"], str(st["path"])),
+                     "rounds": st["text_rounds"] + st["break_rounds"] + st["doubling_rounds"], "radix_passes": st["radix_passes"],
+                     "period": st["period"], "kernel_launches": st["kernel_launches"],
+                     "sa_sha256_matches_reference": sha}
+    return out, ok
+
+
+def inverse_leg(bwt_t, base, x_t):
+    """The inverse of the graded block (A8 + A9), after the timed region: one warm-up + best of 3, output compared with x."""
+    import torch
+    import pyarchon
+    n = x_t.numel()
+    out_t = torch.empty(n, dtype=torch.uint8, device=x_t.device)
+    best, st = None, None
+    for r in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pyarchon.inverse_dev(bwt_t, base, out_t)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if r and (best is None or dt < best):
+            best, st = dt, pyarchon.stats(x_t.device.index or 0)
+    same = bool(torch.equal(out_t, x_t))
+    return {"ms": round(best * 1e3, 3), "MB_s": round(n / 1e6 / best, 1), "hops_per_s": round(n / best, 0),
+            "frac_B17": round(17.0 * n / best / 1e9 / HBM_PEAK_GBS, 4), "ms_lf_build": round(st["ms_lf_build"], 3),
+            "ms_lf_walk": round(st["ms_lf_walk"], 3), "chains": st["walk_chains"], "kernel_launches": st["kernel_launches"],
+            "equals_input": same}, same
 
 
 def main():
@@ -130,6 +212,8 @@ def main():
     ap.add_argument("--block-mib", type=int, default=256, help="block size per GPU (BASELINE config: 256)")
     ap.add_argument("--shape", default="random", help="random|dna|text|a|ab|motif (graded config: random)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mib", type=int, default=1 << 20, help="bound the CPU baseline to the first so many MiB of the block (default: the whole block)")
+    ap.add_argument("--no-shapes", action="store_true", help="skip the other named shapes and the inverse behind the timed region (N=1 runs them by default)")
     ap.add_argument("--no-sa", action="store_true", help="emit BWT only (the metric is quoted WITH the SA)")
     ap.add_argument("--gather-root", default="rotate", help="rotate (step k gathers on rank k mod N: no GPU takes in N-1 payloads "
                     "every step) | 0 (always rank 0)")
@@ -296,6 +380,7 @@ def main():
             per_step = last["radix_pass_timed"]
             bpi_dom = B_RADIX_PASS
         achieved = bpi_dom * n / (t_pass_ms * 1e-3) / 1e9 if t_pass_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(last["path"], n, args.shape, kname)
         dev_ms = float(np.mean([s["ms_total"] for s in stage]))
         line = {
             "metric": "forward-BWT MB/s on 256 MB block (SA bit-exact vs a7 order)",
@@ -334,7 +419,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic(last["path"], n, args.shape, kname),
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "launch_ms": round(t_pass_ms, 4),
                 "launches_per_step": per_step,
                 "algorithmic_bytes_per_launch": bpi_dom * n,
@@ -344,7 +430,7 @@ def main():
                 "device_ms_per_block": round(dev_ms, 3),
                 "algorithmic_bytes_per_input_byte": B_FWD_CFG2,
                 "frac_of_hbm_roofline": round(B_FWD_CFG2 * n / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dev_ms > 0 else None,
-                "path": "streaming (hist16, 2 LSB passes, in-LDS bucket sort)" if last["path"] == 1 else "7 LSB passes + doubling",
+                "path": PATH_NAMES.get(last["path"], str(last["path"])),
                 "ms_hist": round(last["ms_hist"], 3), "ms_sort": round(last["ms_sort"], 3),
                 "ms_pass_text": round(last["ms_pass_text"], 3), "ms_pass_rec": round(last["ms_pass_rec"], 3),
                 "ms_local_sort": round(last["ms_local_sort"], 3), "ms_resolve": round(last["ms_resolve"], 3),
@@ -358,8 +444,16 @@ def main():
                 "unresolved_initial": last["unresolved_initial"], "kernel_launches": last["kernel_launches"],
             },
         }
+        if world == 1 and dist is None and not args.no_shapes:
+            # behind the timed region: the other named shapes at this block size and the inverse of the graded block, each gated
+            inv, inv_ok = inverse_leg(own_last[:n], int(own_last[n:].view(torch.int32).item()), x_t)
+            line["inverse"] = inv
+            shapes, shapes_ok = extra_shapes(n, dev, [sh for sh in EXTRA_SHAPES if sh != args.shape])
+            line["shapes"] = shapes
+            ok = ok and inv_ok and shapes_ok
+            line["config"]["gates_passed"] = ok
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(n)
+            line["cpu_baseline"] = cpu_baseline(n, args.cpu_sample_mib)
             # informational, NOT measured on this host and never part of cpu_baseline / vs_baseline: a7 slows down with the block
             # size; what it took on the WHOLE block of the metric when the reference digests were made (development container)
             full = reference_digest("random", 0, n)

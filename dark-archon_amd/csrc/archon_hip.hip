@@ -5,6 +5,7 @@
 #include "radix_sort.hiph"
 #include "bucket_sort.hiph"
 #include "forward.hiph"
+#include "periodic.hiph"
 #include "rounds.hiph"
 #include "rank_writer.hiph"
 #include "mid_rounds.hiph"
@@ -192,6 +193,10 @@ static uint32_t h16_parts(int dev) { return eff_pass_ranges(dev) > 256u ? (uint3
 // groups the B list / a mid directory can hold: a group of the B list is longer than the S list's limit or straddles a
 // tile of the sweep that made it (at most one per tile)
 static size_t mid_dir_cap(uint32_t n) { return (size_t)n / 512 + 64; }
+// The last bytes of the first-tier arena are never bump-allocated: the closed form of a clean periodic block (periodic.hiph)
+// keeps the nested transform's results there -- suffix array, BWT and row offsets of the 2p-byte block, p <= 65 536 --
+// while the nested call uses the arena from its bottom.
+static constexpr size_t kClosedTail = 2u << 20;
 // Tier 1: what every block needs (the first stage and its tables).  Tier 2: what only the general stage needs.
 static size_t forward_stage1_bytes(uint32_t n, int dev, bool own_sa)
 {
@@ -212,6 +217,7 @@ static size_t forward_stage1_bytes(uint32_t n, int dev, bool own_sa)
     add(sizeof(uint4) * (size_t)bs::kMaxRanges * bs::kTrashWords);
     add(4 * (size_t)h16_parts(dev) * 32768u);        // partial two-byte counts, one table per workgroup of the count
     add(4 * 1024);                            // counts, starts, ticket, err, base, totals, TieCtl
+    add(kClosedTail);
     return b + (1u << 16);
 }
 static size_t forward_stage2_bytes(uint32_t n)
@@ -746,8 +752,10 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     return ARCHON_OK;
 }
 
+// depth: 0 = a caller's block, 1 = the 2p-byte block of a clean periodic block's closed form (periodic.hiph): its own event
+// banks, no closed form of its own
 static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n, uint32_t *d_sa_user,
-                       uint8_t *d_bwt, uint32_t *d_base_out)
+                       uint8_t *d_bwt, uint32_t *d_base_out, int depth = 0)
 {
     ARCHON_TRY(ctx_ensure_arena(c, forward_stage1_bytes(n, c->dev, d_sa_user == nullptr)));
     c->arena_reset();
@@ -834,8 +842,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     }
     uint32_t *sa = d_sa_user ? d_sa_user : B.sa_own;
 
-    StageTimer tm(c, 0, s);
-    StageTimer pt(c, 24, s);
+    StageTimer tm(c, 72 * depth, s);
+    StageTimer pt(c, 72 * depth + 24, s);
     const int e0 = tm.mark();
 
     // A2 / bucket setup: the two-byte count (a4 compute(), archon.c:146-161) and its scans.  The count
@@ -860,7 +868,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     if (R > (uint32_t)bs::kMaxRanges) { set_error("block of %u bytes needs %u pass ranges (max %d)", n, R, bs::kMaxRanges); return ARCHON_E_INTERNAL; }
     uint32_t *rhist = B.rhist;                  // [R][256], reused by both passes
     // Q = symbols per key byte of the streaming stage: 1 = plain bytes; 2/4/8 = compacted alphabet (below)
-    StageTimer ps(c, 48, s);                            // streaming stage: pass A, pass B (their own HIP events)
+    StageTimer ps(c, 72 * depth + 48, s);               // streaming stage: pass A, pass B (their own HIP events)
     int iA0 = -1, iA1 = -1, iB0 = -1, iB1 = -1;
     uint2 *A_R = reinterpret_cast<uint2 *>(B.keyA);     // pass A out: {K, I} records + the first-key-byte stream
     uint8_t *A_B1 = reinterpret_cast<uint8_t *>(B.valA);
@@ -871,6 +879,29 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // bucket-per-workgroup pass B (Prep::aligned) needs 256 workgroups and enough tiles per bucket to matter
     const uint32_t allow_aligned = (n >= (1u << 24) && !route_off(kRtNoAligned) && g_opt[c->dev].pass_b_buckets.load()) ? 1u : 0u;
     int e1 = -1;
+    // Clean periodic blocks (periodic.hiph): the period probe and the comparison of the whole text with itself p further down are
+    // queued in FRONT of the count -- device-conditional, a block without a voted period pays three empty launches -- and their
+    // verdict comes to the host with the block's first round trip; k_rows_scan reads it too and lets the streaming kernels return.
+    const int forced = g_route.force_path;       // (tests): 0 = 7-pass route, 1 = streaming stage, -1 = the block decides
+    const bool closed_ok = depth == 0 && forced < 0 && n >= (1u << 16) && !route_off(kRtNoPeriodProbe) && !route_off(kRtNoChains) && !route_off(kRtNoClosedForm);
+    uint32_t *pres = small + 610;                // [0] period, [1] votes, [2] the text breaks it, [3] the whole text was compared
+    bool probe_queued = false;
+    auto queue_probe = [&]() -> int {
+        ARCHON_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)pres, (int)0xFFFFFFFFu, 1, s));      // (the votes and flags behind it are zero: `small` was cleared)
+        hipLaunchKernelGGL(fwd::k_period_find, dim3(fwd::kPeriodSearch / 256), dim3(256), 0, s, d_x, n, pres);
+        hipLaunchKernelGGL(fwd::k_period_vote, dim3(fwd::kPeriodVotes / 256), dim3(256), 0, s, d_x, n, pres);
+        c->launches += 2;
+        if (closed_ok) {
+            hipLaunchKernelGGL(pf::k_period_clean, dim3(kNumCU * 8), dim3(256), 0, s, d_x, n, pres);
+            ++c->launches;
+        }
+        probe_queued = true;
+        return ARCHON_OK;
+    };
+    auto fetch_probe = [&]() -> int {            // (with the round trip that follows)
+        if (probe_queued) ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 530, pres, pf::kCleanWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        return ARCHON_OK;
+    };
     auto count16 = [&](int Q, const uint8_t *src, bool force_stream, bool probe = false, bool hot = false) -> int {
         uint32_t *d_suspect = probe ? &B.prep->suspect : nullptr;
         ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, (size_t)(reinterpret_cast<char *>(&B.prep->rowtot[0]) - reinterpret_cast<char *>(B.hist16)), s));
@@ -887,7 +918,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_hist16<8>), grid, block, 0, s, src, n, B.h16part, B.hist16, tpr * kTileItems, rhist, d_suspect, sub);
         static_assert(bs::kMaxRanges <= 1024, "four ranges per lane in the column half of k_rows_sum_total");
         hipLaunchKernelGGL(bs::k_rows_sum_total, dim3(512), dim3(256), 0, s, B.hist16, B.h16part, nparts, B.prep, (uint32_t)bs::kLsCap, rhist, R);
-        hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep, force_stream ? 1u : 0u, allow_aligned, d_ctl, (uint32_t)kTieListCap, n);
+        hipLaunchKernelGGL(bs::k_rows_scan, dim3(256), dim3(256), 0, s, B.hist16, B.prep, force_stream ? 1u : 0u, allow_aligned, d_ctl, (uint32_t)kTieListCap, n,
+                           probe_queued ? pres : nullptr);
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 3;
         e1 = tm.mark();
@@ -956,6 +988,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 20, B.sc.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         e3 = tm.mark();
         if (Q == 1) ARCHON_TRY(fetch_byte_counts());              // free with the round trip; used only by skewed blocks
+        ARCHON_TRY(fetch_probe());
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         memcpy(&h_ctl, c->h_mail, sizeof h_ctl);
         big_items = h_ctl.big_items;
@@ -965,6 +998,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     auto count_wait = [&]() -> int {             // routes that need the count on the host before going on
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 64, &B.prep->big_items, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         ARCHON_TRY(fetch_byte_counts());
+        ARCHON_TRY(fetch_probe());
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         big_items = c->h_mail[64];
         return ARCHON_OK;
@@ -988,7 +1022,6 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ++c->launches;
         return ARCHON_OK;
     };
-    const int forced = g_route.force_path;       // (tests): 0 = 7-pass route, 1 = streaming stage, -1 = the block decides
     int path;
     int Q = 1;                                   // symbols per key byte on the streaming path
     const bool probe = forced < 0 && !route_off(kRtNoProbe);
@@ -1010,13 +1043,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 520, d_x + (n - 8), 8, hipMemcpyDeviceToHost, s));
         tail_fetched = true;
         if (n >= (1u << 16) && !route_off(kRtNoPeriodProbe)) {
-            uint32_t *pres = small + 610;
-            c->h_mail[528] = 0xFFFFFFFFu; c->h_mail[529] = 0;
-            ARCHON_HIP_TRY(hipMemcpyAsync(pres, c->h_mail + 528, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(fwd::k_period_find, dim3(fwd::kPeriodSearch / 256), dim3(256), 0, s, d_x, n, pres);
-            hipLaunchKernelGGL(fwd::k_period_vote, dim3(fwd::kPeriodVotes / 256), dim3(256), 0, s, d_x, n, pres);
-            ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 530, pres, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            c->launches += 2;
+            ARCHON_TRY(queue_probe());
+            ARCHON_TRY(fetch_probe());
             period_probed = true;
         }
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
@@ -1027,6 +1055,10 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         have_byte_counts = true;
         path = 0;
     } else {
+    if (closed_ok) {
+        ARCHON_TRY(queue_probe());
+        period_probed = true;
+    }
     ARCHON_TRY(count16(1, d_x, forced == 1, probe));
     if (forced == 0) {
         ARCHON_TRY(count_wait());
@@ -1035,6 +1067,50 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ARCHON_TRY(streaming(1, d_x));
         path = (forced == 1 || (uint64_t)big_items * 2 <= n) ? 1 : 0;
     }
+    }
+    if (closed_ok && period_probed && c->h_mail[530] != 0xFFFFFFFFu && c->h_mail[533] == 1u && c->h_mail[532] == 0u) {
+        // ---- a clean periodic block (periodic.hiph): x[i] == x[i-p] for every i >= p (k_period_clean compared all of it), p minimal
+        // (the smallest distance at which the block's middle window recurs: a smaller period would recur there too), n >= 16 p.
+        // Sort the block's first 2p bytes -- the ordinary transform, nested -- and expand its suffix array.
+        const uint32_t p = c->h_mail[530], m2 = 2u * p;
+        char *tail = c->arena + ((c->arena_bytes - kClosedTail) & ~size_t(255));
+        uint32_t *sa2 = reinterpret_cast<uint32_t *>(tail);
+        uint32_t *off = sa2 + ((m2 + 63u) & ~63u);
+        uint8_t *bwt2 = reinterpret_cast<uint8_t *>(off + ((m2 + 1u + 63u) & ~63u));
+        uint32_t *base2 = reinterpret_cast<uint32_t *>(bwt2 + ((m2 + 255u) & ~255u));
+        if ((size_t)(reinterpret_cast<char *>(base2 + 64) - tail) > kClosedTail || (uint64_t)p * pf::kMinPeriods + 64u > n) {
+            set_error("closed form: period %u of a block of %u bytes does not fit its scratch", p, n);
+            return ARCHON_E_INTERNAL;
+        }
+        const uint32_t launches0 = c->launches;
+        const bool x_in_arena = d_x == B.xa;
+        ARCHON_TRY(forward_run(c, s, d_x, m2, sa2, bwt2, base2, depth + 1));      // (c->stats, c->launches, the arena: the nested call's from here on)
+        const uint32_t launches1 = c->stats.kernel_launches;
+        const uint64_t arena1 = c->stats.arena_bytes;
+        c->arena_reset();
+        if (x_in_arena) (void)c->alloc<uint8_t>((size_t)n + 64);                  // the aligned copy of the text stays where it is
+        const uint32_t ntiles = div_up(n, pf::kTile);
+        uint32_t *tile_lo = c->alloc<uint32_t>((size_t)ntiles + 2);
+        if (!tile_lo) { set_error("arena exhausted (closed form)"); return ARCHON_E_NOMEM; }
+        hipLaunchKernelGGL(pf::k_offsets, dim3(1), dim3(1024), 0, s, sa2, m2, p, n, off);
+        hipLaunchKernelGGL(pf::k_tiles, dim3(div_up(ntiles + 1, 256)), dim3(256), 0, s, off, m2, ntiles, tile_lo);
+        hipLaunchKernelGGL(pf::k_expand, dim3(ntiles), dim3(256), 0, s, off, sa2, bwt2, tile_lo, m2, p, n, d_x, d_sa_user, d_bwt, d_base_out);
+        ARCHON_HIP_TRY(hipGetLastError());
+        const int e_end = tm.mark();
+        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, off + m2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        if (c->h_mail[0] != n) { set_error("closed form: the classes of period %u hold %u rows of %u", p, c->h_mail[0], n); return ARCHON_E_INTERNAL; }
+        memset(&st, 0, sizeof st);
+        st.n = n;
+        st.path = 2;
+        st.period = p;
+        st.chain_items = n;
+        st.kernel_launches = c->launches = launches0 + launches1 + 3;
+        st.arena_bytes = arena1 > c->arena_off ? arena1 : c->arena_off;
+        st.ms_hist = tm.ms(e0, e1);
+        st.ms_sort = tm.ms(e1, e_end);
+        st.ms_total = tm.ms(e0, e_end);
+        return ARCHON_OK;
     }
     constexpr uint32_t kPackSigma = 32;          // alphabets up to this many distinct bytes sort on packed keys
     uint32_t sigma = 0, bits = 8;
@@ -2140,6 +2216,7 @@ int archon_hip_test_route(const char *name, long value)
         {"NO_PACK_STREAM", kRtNoPackStream}, {"NO_PAIR_CHAINS", kRtNoPairChains}, {"NO_PERIOD_HINT", kRtNoPeriodHint},
         {"NO_BREAK_ROUND", kRtNoBreakRound}, {"NO_PERIOD_PROBE", kRtNoPeriodProbe}, {"NO_PERIOD_STREAM", kRtNoPeriodStream}, {"NO_PROBE", kRtNoProbe},
         {"NO_RANK_WRITER", kRtNoRankWriter}, {"NO_TEXT_ROUNDS", kRtNoTextRounds}, {"NO_MID", kRtNoMid}, {"NO_SHALLOW", kRtNoShallow},
+        {"NO_CLOSED_FORM", kRtNoClosedForm},
     };
     if (!strcmp(name, "RESET")) { g_route = Route(); return ARCHON_OK; }
     if (!strcmp(name, "FORCE_PATH")) { g_route.force_path = value < 0 ? -1 : (value ? 1 : 0); return ARCHON_OK; }

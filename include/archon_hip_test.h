@@ -15,7 +15,7 @@
  *   INV_ROWS                            inverse: 0 = every lane of the walk stores its own 16 bytes, 1 / 2 = slabs written by quads through
  *                                       128- / 64-byte rows of LDS, -1 = the product's rule (rows above 128 MiB)
  *   NO_ALIGNED NO_BREAK_ROUND NO_CHAINS NO_DEEP_HINT NO_PACK NO_PACK_STREAM NO_PAIR_CHAINS NO_PERIOD_HINT NO_PERIOD_PROBE
- *   NO_PERIOD_STREAM NO_PROBE NO_RANK_WRITER NO_TEXT_ROUNDS NO_MID NO_SHALLOW      nonzero switches the named step off
+ *   NO_PERIOD_STREAM NO_PROBE NO_RANK_WRITER NO_TEXT_ROUNDS NO_MID NO_SHALLOW NO_CLOSED_FORM      nonzero switches the named step off
  * Returns 0, or ARCHON_E_ARG for an unknown name / a value out of range.  Process-wide; not thread-safe against
  * concurrent transforms (tests run one at a time).
  */

@@ -226,10 +226,14 @@ def _repeat_cases():
     }
 
 
+@pytest.mark.parametrize("closed", ["closed_form", "shortcut"])
 @pytest.mark.parametrize("name", sorted(_repeat_cases()))
-def test_long_repeats(archon, oracle, name):
-    """Gauntlet-style periodic inputs (BASELINE.json configs[2]): the run shortcut (k_chain_*) and the doubling
-    rounds behind it must give the a7 order whatever mix of runs, periods and run boundaries the block holds."""
+def test_long_repeats(archon, oracle, name, closed, monkeypatch):
+    """Gauntlet-style periodic inputs (BASELINE.json configs[2]): the closed form of clean periodic blocks (periodic.hiph),
+    the run shortcut (k_chain_*) and the doubling rounds behind it must give the a7 order whatever mix of runs, periods
+    and run boundaries the block holds."""
+    if closed == "shortcut":
+        monkeypatch.setenv("ARCHON_NO_CLOSED_FORM", "1")
     x = _repeat_cases()[name]
     sa, bwt, base = archon.forward(x)
     P, B, b0 = oracle.forward(x)
@@ -239,7 +243,8 @@ def test_long_repeats(archon, oracle, name):
 
 @pytest.mark.parametrize("route", ["streaming", "lsb"])
 def test_long_repeats_use_the_shortcut(archon, monkeypatch, route):
-    """periodic blocks: two streaming passes + the run shortcut (default), or three LSB passes + the shortcut"""
+    """periodic blocks without the closed form: two streaming passes + the run shortcut, or three LSB passes + the shortcut"""
+    monkeypatch.setenv("ARCHON_NO_CLOSED_FORM", "1")
     if route == "lsb":
         monkeypatch.setenv("ARCHON_NO_PERIOD_STREAM", "1")
     x = np.tile(np.frombuffer(b"ab", np.uint8), 1 << 20)
@@ -255,12 +260,88 @@ def test_long_repeats_lsb_route(archon, oracle, name, hint, monkeypatch):
     """the same gauntlet with the periodic blocks kept on the 7-pass route (ordered groups): the period from the driver's
     probe, or -- probe's answer withheld -- from a sample of the neighbour gaps inside the tied groups"""
     monkeypatch.setenv("ARCHON_NO_PERIOD_STREAM", "1")
+    monkeypatch.setenv("ARCHON_NO_CLOSED_FORM", "1")
     if hint == "gaps":
         monkeypatch.setenv("ARCHON_NO_PERIOD_HINT", "1")
     x = _repeat_cases()[name]
     sa, bwt, base = archon.forward(x)
     P, B, b0 = oracle.forward(x)
     assert (sa == P).all() and (bwt == B).all() and base == b0
+
+
+def _clean_periodic(p, n, alphabet, seed):
+    """a block of n bytes with minimal period p over the given byte values (the motif is made primitive: its last byte
+    differs from every other when the draw happens to repeat)"""
+    rng = np.random.default_rng(seed)
+    alpha = np.array(alphabet, np.uint8)
+    motif = alpha[rng.integers(0, alpha.size, size=p)]
+    if p > 1:
+        if alpha.size < 2:
+            raise ValueError("a period above 1 needs two byte values")
+        # a^(p-1) b style tail guarantees primitivity: make position p-1 differ from position 0 and break any inner period
+        motif[: p - 1] = alpha[rng.integers(0, alpha.size, size=p - 1)]
+        for d in range(1, p):
+            if p % d == 0 and np.array_equal(np.tile(motif[:d], p // d), motif):
+                motif[p - 1] = alpha[(int(np.where(alpha == motif[p - 1])[0][0]) + 1) % alpha.size]
+                break
+    return np.tile(motif, n // p + 2)[:n].copy()
+
+
+_CLOSED = [(p, extra, alpha_name) for p in (1, 2, 3, 7, 1000, 4099, 65521) for extra in (0, 1, "p-1", "half")
+           for alpha_name in ("bytes", "ff", "ab")]
+
+
+@pytest.mark.parametrize("route", ["big", "small"])
+@pytest.mark.parametrize("p,extra,alpha_name", _CLOSED)
+def test_clean_periodic_closed_form(archon, oracle, p, extra, alpha_name, route, request, monkeypatch):
+    """a block with x[i] == x[i-p] everywhere is written down from the suffix array of its first 2p bytes
+    (periodic.hiph) -- every period class, ragged ends (n mod p = 0, 1, p-1, p/2), alphabets with 0xFF (the end of the
+    block sorts above it) and with two letters (classes that agree for long), against the oracle; on the route of big
+    blocks (two-byte count in front) and on the product's small-block route (byte count in front)."""
+    if p == 1 and extra in ("p-1", "half"):
+        pytest.skip("n mod 1 is 0")
+    if p == 1 and alpha_name == "ab":
+        pytest.skip("one letter")
+    alphabet = {"bytes": list(range(256)), "ff": [0, 254, 255], "ab": [97, 98]}[alpha_name]
+    periods = 40 if p < 4099 else 17
+    n = max(p * periods, 70000 // p * p)
+    n += {0: 0, 1: 1, "p-1": p - 1, "half": p // 2}[extra]
+    if route == "small":
+        monkeypatch.setenv("ARCHON_SMALL_BLOCK", "-1")
+    x = _clean_periodic(p, n, alphabet, 1000 * p + len(alphabet))
+    sa, bwt, base = archon.forward(x)
+    st = archon.stats()
+    P, B, b0 = oracle.forward(x)
+    assert (sa == P).all()
+    assert (bwt == B).all() and base == b0
+    assert st["path"] == 2 and st["period"] == p and st["chain_items"] == n and st["doubling_rounds"] == 0, st
+    # ... and the same block with one defect takes the general route (the closed form certifies the WHOLE text)
+    y = x.copy()
+    y[n - 1 - (n // 3)] ^= 1
+    sa, bwt, base = archon.forward(y)
+    P, B, b0 = oracle.forward(y)
+    assert archon.stats()["path"] != 2
+    assert (sa == P).all() and (bwt == B).all() and base == b0
+
+
+def test_closed_form_without_sa_and_unaligned(archon, oracle):
+    """the expansion with no suffix array asked for, and on a text that starts at an odd address (the aligned copy lives in
+    the arena the nested transform also uses)"""
+    import torch
+    x = _clean_periodic(1000, 1000 * 300 + 17, list(range(256)), 5)
+    _, bwt, base = archon.forward(x, want_sa=False)
+    P, B, b0 = oracle.forward(x)
+    assert (bwt == B).all() and base == b0 and archon.stats()["path"] == 2
+    buf = torch.zeros(x.size + 64, dtype=torch.uint8, device="cuda")
+    for shift in (1, 7):
+        xt = buf[shift: shift + x.size]
+        xt.copy_(torch.from_numpy(x))
+        sa_t = torch.empty(x.size, dtype=torch.int32, device="cuda")
+        bwt_t = torch.empty(x.size, dtype=torch.uint8, device="cuda")
+        base_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+        archon.forward_dev(xt, sa_t, bwt_t, base_t)
+        assert archon.stats()["path"] == 2
+        assert (sa_t.cpu().numpy().astype(np.uint32) == P).all() and (bwt_t.cpu().numpy() == B).all() and int(base_t.item()) == b0
 
 
 def _defect_cases():
@@ -519,13 +600,13 @@ def test_max_block(archon, shape):
     archon.forward_dev(x_t, sa_t, bwt_t, base_t)
     st = archon.stats()
     # beyond ~300 MB the two-byte buckets of even a uniform block exceed the in-LDS sort (4608 items): 7-pass route;
-    # a periodic block takes the two streaming passes whatever its size (its buckets go on as groups tied at depth 2)
-    assert st["path"] == (0 if shape == "random" else 1)
+    # a clean periodic block is written down in closed form whatever its size (path 2)
+    assert st["path"] == (0 if shape == "random" else 2)
     base = int(base_t.item())
     assert int(sa_t[base].item()) == n
     if shape == "a":      # a^N: the order is N, N-1, ..., 1
         assert torch.equal(sa_t, torch.arange(n, 0, -1, dtype=torch.int32, device="cuda")) and base == 0
-        assert st["doubling_rounds"] == 0 and st["period"] == 1
+        assert st["doubling_rounds"] == 0 and st["period"] == 1 and st["chain_items"] == n
     assert archon.validate_dev(x_t, sa_t)
     del sa_t
     out_t = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -670,6 +751,7 @@ def test_periodic_blocks_with_many_pass_ranges(archon, oracle, monkeypatch, rang
     deferred buckets and the run shortcut with the passes cut into odd ranges"""
     monkeypatch.setenv("ARCHON_PASS_RANGES", ranges)
     monkeypatch.setenv("ARCHON_NO_ALIGNED", "1")
+    monkeypatch.setenv("ARCHON_NO_CLOSED_FORM", "1")
     rng = np.random.default_rng(5)
     for x in (np.tile(np.frombuffer(b"ab", np.uint8), 1 << 20), np.full(3000001, 97, np.uint8),
               np.tile(rng.integers(0, 256, size=37, dtype=np.uint8), 60000)):

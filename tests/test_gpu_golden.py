@@ -44,7 +44,8 @@ def test_hip_vs_reference_small_product_route(archon, case):
     assert _sha(np.ascontiguousarray(sa, "<u4")) == case["sha256_P"]
     assert _sha(bwt, int(base).to_bytes(4, "little")) == case["sha256_bwt_base"]
     if 8 <= case["n"] < (8 << 20):
-        assert archon.stats()["path"] == 0
+        periodic = case["shape"] in ("a", "ab", "motif") and case["n"] >= (1 << 16)      # clean periodic blocks: the closed form (path 2)
+        assert archon.stats()["path"] == (2 if periodic else 0)
 
 
 @pytest.mark.parametrize("case", GOLDEN["cases"], ids=lambda c: "%s-%d" % (c["shape"], c["n"]))
@@ -87,7 +88,8 @@ def test_hip_vs_reference_full_size(archon, case):
 
 
 @pytest.mark.parametrize("shape,route", [("random", "0"), ("dna", "0"), ("a", "0"), ("ab", "0"), ("random_copy", "0"),
-                                         ("text", "1"), ("prose", "1"), ("motif", "1"), ("motif_defects", "1")])
+                                         ("text", "1"), ("prose", "1"), ("motif", "1"), ("motif_defects", "1"),
+                                         ("a", "shortcut"), ("ab", "shortcut"), ("motif", "shortcut")])
 def test_hip_vs_reference_full_size_other_route(archon, shape, route, monkeypatch):
     """the full-size reference digests again with the first stage the block would NOT take by itself: the 7-pass route on
     the blocks that stream by themselves (ARCHON_FORCE_PATH=0: random, DNA on packed keys, the periodic ones, the block with a
@@ -95,7 +97,11 @@ def test_hip_vs_reference_full_size_other_route(archon, shape, route, monkeypatc
     ones (=1): every route gives the reference's bytes at the graded size, not only at n / 8"""
     import torch
     case = [c for c in GOLDEN_FULL["cases"] if c["shape"] == shape and c["block"] == 0][0]
-    monkeypatch.setenv("ARCHON_FORCE_PATH", route)
+    if route == "shortcut":          # the clean periodic blocks without their closed form: streaming passes + the run shortcut (path 1)
+        monkeypatch.setenv("ARCHON_NO_CLOSED_FORM", "1")
+        route = "1"
+    else:
+        monkeypatch.setenv("ARCHON_FORCE_PATH", route)
     n = case["n"]
     x_t = torch.from_numpy(S.gen_shape(shape, n, block=0)).cuda()
     sa_t = torch.empty(n, dtype=torch.int32, device="cuda")

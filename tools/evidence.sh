@@ -13,9 +13,9 @@ if [ $part = a ]; then
 timeout -k 10 400 python3 bench.py --steps 20 --warmup 2 > $out/bench_line.json 2> $out/bench.err || exit 1
 echo "bench done"
 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 2 --no-cpu-baseline > $out/bench_line_torchrun_world1.json 2> $out/bench_w1.err || exit 1
-timeout -k 10 300 python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline > $out/bench_line_same_box_again.json 2>> $out/bench.err || exit 1
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-shapes > $out/bench_line_same_box_again.json 2>> $out/bench.err || exit 1
 echo "world-1 done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-shapes > $out/stats.log 2>&1 || exit 1
 cp $(ls $out/stats/*/*_kernel_stats.csv | tail -1) $out/kernel_stats.csv
 echo "stats done"
 bash tools/pmc.sh $tag/pmc fetch FETCH_SIZE -- 256 random 3 || exit 1

@@ -2,7 +2,7 @@
 # the round's last call: the whole -m gpu suite, then the inverse's evidence on the last library
 set -o pipefail
 export TMPDIR=/tmp
-out=gpurun_out/r04_final; mkdir -p $out
+out=gpurun_out/${1:-final}; mkdir -p $out
 timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $out/tests_final.log 2>&1; rc=$?; echo "tests rc=$rc"
 tail -2 $out/tests_final.log
 [ $rc = 0 ] || exit 1
