@@ -217,6 +217,8 @@ def main():
     ap.add_argument("--no-sa", action="store_true", help="emit BWT only (the metric is quoted WITH the SA)")
     ap.add_argument("--gather-root", default="rotate", help="rotate (step k gathers on rank k mod N: no GPU takes in N-1 payloads "
                     "every step) | 0 (always rank 0)")
+    ap.add_argument("--gather-threaded", type=int, default=1, help="1: the gather is issued from the pipe's helper thread (default) | 0: from "
+                    "the calling thread (A/B runs)")
     ap.add_argument("--pass-ranges", type=int, default=-1, help="library option pass_ranges (default: one per CU at N=1, 1024 at N>1)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the measured configuration) | gloo (rehearsal of the N>1 "
                     "control flow on fewer GPUs than ranks: ranks share devices, the gather is staged through host memory)")
@@ -257,7 +259,8 @@ def main():
     sa_t = None if args.no_sa else torch.empty(n, dtype=torch.int32, device=dev)
     # BWT || baseId (LE), double-buffered: the gather of step k runs on RCCL's stream while step k+1 sorts
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
-    pipe = archon_shard.GatherPipe(dist, rank, world, n + 4, dev, via_host=(args.backend != "nccl"), rotate=(args.gather_root == "rotate"))
+    pipe = archon_shard.GatherPipe(dist, rank, world, n + 4, dev, via_host=(args.backend != "nccl"), rotate=(args.gather_root == "rotate"),
+                                   threaded=bool(args.gather_threaded))
     pass_ranges = 0
     if world > 1:
         # RCCL's send/recv kernels hold CUs while the gather of step k overlaps the sort of step k+1, and a pass

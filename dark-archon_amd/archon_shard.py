@@ -97,10 +97,14 @@ class GatherPipe:
             if job is None:
                 return
             k, step, ev = job
-            try:
-                self._issue(k, step)
-            except Exception as e:      # noqa: BLE001  (reported by the next wait on this buffer)
-                self.error = e
+            if self.error is None:
+                try:
+                    self._issue(k, step)
+                except Exception as e:      # noqa: BLE001
+                    # The first failure ends the pipe: no later gather is issued (a rank that went on issuing collectives its
+                    # peers never match would block them until the NCCL timeout), every job still queued has its event set,
+                    # and the owner thread learns at its very next call (submit / next_buffer / drain all raise self.error).
+                    self.error = e
             ev.set()
 
     def _wait(self, k):
@@ -123,6 +127,8 @@ class GatherPipe:
 
     def submit(self):
         """the payload of the current step is complete in its buffer (the producer has synchronised): gather it"""
+        if self.error is not None:
+            raise self.error
         k = self.step_no & 1
         step = self.step_no
         self.step_no += 1
@@ -141,7 +147,12 @@ class GatherPipe:
             self._wait(k)
 
     def close(self):
-        self.drain()
+        try:
+            self.drain()
+        finally:
+            self._stop()
+
+    def _stop(self):
         if self.queue is not None:
             self.queue.put(None)
             self.thread.join(10)

@@ -381,8 +381,8 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     {
         uint32_t init[fwd::kMcWords] = {};
         init[fwd::kMcTop] = init[fwd::kMcTop + 1] = n;
-        memcpy(c->h_mail + 4200, init, sizeof init);
-        ARCHON_HIP_TRY(hipMemcpyAsync(B.mc, c->h_mail + 4200, sizeof init, hipMemcpyHostToDevice, s));
+        memcpy(c->h_mail + 4400, init, sizeof init);                 // (words of their own: 4200.. take the rounds' counters)
+        ARCHON_HIP_TRY(hipMemcpyAsync(B.mc, c->h_mail + 4400, sizeof init, hipMemcpyHostToDevice, s));
     }
     int cs = 0;
     unsigned long long *fg_status = reinterpret_cast<unsigned long long *>(B.sc.d_status);
@@ -452,10 +452,10 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         const int nxt = cur ^ 1;
         if (mid) {
             // the next list starts empty: no groups, its items from the top of the buffer downwards
-            c->h_mail[4200] = 0; c->h_mail[4201] = n;
-            ARCHON_HIP_TRY(hipMemcpyAsync(B.mc + fwd::kMcSmall + nxt, c->h_mail + 4200, sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            ARCHON_HIP_TRY(hipMemcpyAsync(B.mc + fwd::kMcLarge + nxt, c->h_mail + 4200, sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            ARCHON_HIP_TRY(hipMemcpyAsync(B.mc + fwd::kMcTop + nxt, c->h_mail + 4201, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            // (fills, not copies out of the mailbox: the mailbox words 4200.. receive this round's counters further down)
+            ARCHON_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(B.mc + fwd::kMcSmall + nxt), 0, 1, s));
+            ARCHON_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(B.mc + fwd::kMcLarge + nxt), 0, 1, s));
+            ARCHON_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(B.mc + fwd::kMcTop + nxt), (int)n, 1, s));
             // (a B list whose groups average twice the largest mid group -- a periodic block with defects: one group per phase of
             //  the period -- goes to the global sort as it is: the two sweeps that would deal it out find nothing to hand over)
             if (mb && (uint64_t)bgroups * (2u * fwd::kMidLargeCap) > mb) {

@@ -32,7 +32,7 @@ static void *block_alloc(size_t bytes, bool *pinned)
 }
 
 Archon::Archon(const t_index Nx)
-    : Nmax(Nx), Nreserve(estimateReserve(Nx)), P(NULL), str(NULL), N(0), baseId(0), dev(0), pinned(false), last_rc(0), blk(NULL)
+    : Nmax(Nx), Nreserve(estimateReserve(Nx)), P(NULL), str(NULL), N(0), baseId(0), dev(0), pinned(false), last_rc(0), blk(NULL), resident(false)
 {
     bool p1 = false, p2 = false;
     *const_cast<suffix **>(&P) = static_cast<suffix *>(block_alloc(((size_t)Nmax + Nreserve) * sizeof(suffix), &p1));
@@ -56,7 +56,7 @@ Archon::~Archon()
 
 void Archon::setDevice(int d)
 {
-    if (d != dev && blk) { archon_hip_block_destroy(blk); blk = NULL; }      // what is resident lives on the old device
+    if (d != dev && blk) { archon_hip_block_destroy(blk); blk = NULL; resident = false; }      // what is resident lives on the old device
     dev = d;
 }
 
@@ -70,8 +70,9 @@ bool Archon::validate()
 {
     // The reference walks P and str on the host (archon.cpp:862-874).  Here enCompute has left the block, its suffix array
     // and its BWT on the device: the check runs on what is there -- no 5N-byte upload, no second gather of str[P[i]].
-    // (An object that has not computed anything has nothing resident: the host arrays are checked instead.)
-    last_rc = blk ? archon_hip_block_validate(blk) : ARCHON_E_ARG;
+    // (An object that has not computed anything -- or has read another block since: the reference would then test the old P
+    //  against the new str and fail, archon.cpp:862-874 -- has nothing resident: the host arrays are checked instead.)
+    last_rc = (blk && resident) ? archon_hip_block_validate(blk) : ARCHON_E_ARG;
     if (last_rc == ARCHON_E_ARG) last_rc = archon_hip_validate(str, N, P, dev);
     return last_rc == 1;
 }
@@ -79,6 +80,7 @@ bool Archon::validate()
 int Archon::enRead(FILE *const fx, t_index ns)
 {
     if (ns > Nmax) ns = Nmax;
+    resident = false;               // what the device holds is the previous block
     N = (t_index)fread(str, 1, ns, fx);
     return (int)N;
 }
@@ -91,6 +93,7 @@ int Archon::enCompute()
         if (last_rc != ARCHON_OK) return last_rc;
     }
     last_rc = archon_hip_block_forward(blk, str, N, P, &baseId);
+    resident = last_rc == ARCHON_OK;
     return last_rc;
 }
 
@@ -103,7 +106,7 @@ int Archon::enWrite(FILE *const fx)
     const t_index cap = Nreserve * (t_index)sizeof(suffix);
     for (t_index off = 0; off < N;) {
         const t_index len = N - off < cap ? N - off : cap;
-        last_rc = blk ? archon_hip_block_read_bwt(blk, off, len, bounce) : ARCHON_E_ARG;
+        last_rc = (blk && resident) ? archon_hip_block_read_bwt(blk, off, len, bounce) : ARCHON_E_ARG;
         if (last_rc != ARCHON_OK) return last_rc;
         if (fwrite(bounce, 1, len, fx) != len) return -1;
         off += len;

@@ -19,6 +19,7 @@ class Archon {
     bool pinned;
     int last_rc;
     struct archon_hip_block *blk;   // the object's resident block on the device (x, SA, BWT between enCompute, validate and enWrite)
+    bool resident;                  // blk holds what str / P hold: set by enCompute, cleared by every read into str
 
 public:
     static t_index estimateReserve(const t_index);

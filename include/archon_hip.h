@@ -21,10 +21,13 @@
  *
  * Error model: 0 = ok, negative = ARCHON_E_* below (the reference returns int
  * from every Archon method, archon.h:16-28).  The library owns device memory and
- * streams: two compute contexts per device (arena, staging buffers, stream each),
- * created lazily.  A host thread is bound to one context PER DEVICE: the k-th thread
- * that comes to device d takes context k mod 2 of that device, or the one it names
- * with archon_hip_bind_context.  One thread sees strictly serial behaviour; two
+ * streams: up to eight compute contexts per device (arena, staging buffers, stream each:
+ * about 145 MB of fixed tables plus 27 N .. 96 N of arena for the largest block it has
+ * seen, kept until archon_hip_release), created lazily.  A host thread is bound to one
+ * context PER DEVICE: the k-th thread that comes to device d takes context k mod 2 of
+ * that device (threads never spread over more than two by themselves), or the one it
+ * names with archon_hip_bind_context (0..7: the batch entry points and the container's
+ * worker pools do).  One thread sees strictly serial behaviour; two
  * threads feeding one GPU overlap one block's copies with the other's kernels;
  * separate devices run concurrently.  A context holds NO results between calls:
  * what outlives a call (the resident block of a block-coder object) belongs to an

@@ -70,15 +70,18 @@ def test_block_assignment():
     assert bwt.tolist() == [1, 2, 3] and base == 0x01020304
 
 
-def _pipe_worker(rank, world, port, rotate, q):
+def _pipe_worker(rank, world, port, rotate, q, via_host=True, threaded=True):
     sys.path.insert(0, os.path.join(ROOT, "dark-archon_amd"))
     import archon_shard
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     nbytes, steps = 1000, 5
-    pipe = archon_shard.GatherPipe(dist, rank, world, nbytes, torch.device("cpu"), via_host=True, rotate=rotate)
+    pipe = archon_shard.GatherPipe(dist, rank, world, nbytes, torch.device("cpu"), via_host=via_host, rotate=rotate, threaded=threaded)
     ok = True
+    if not via_host and (rotate or rank == 0):
+        # the branch the RCCL run takes: a root's own slot of the gathered list IS its payload buffer
+        ok = all(pipe.lists[k][rank] is pipe.outs[k] for k in range(2))
     for k in range(steps):
         buf = pipe.next_buffer()
         buf[:] = (17 * k + 3 * rank) % 251               # the payload of (step k, rank)
@@ -90,6 +93,7 @@ def _pipe_worker(rank, world, port, rotate, q):
         if rank == root:
             for r in range(world):
                 ok = ok and bool((got[r] == (17 * k + 3 * r) % 251).all())
+    pipe.close()
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
@@ -109,3 +113,53 @@ def test_gather_pipe_roots(rotate):
         assert p.exitcode == 0
     res = dict(q.get(timeout=10) for _ in range(2))
     assert res == {0: True, 1: True}
+
+
+@pytest.mark.parametrize("threaded", [True, False])
+@pytest.mark.parametrize("rotate", [False, True])
+def test_gather_pipe_aliased_root_slot(rotate, threaded):
+    """the branch bench.py takes over RCCL (no staging through the host) -- the root's own slot of the gathered
+    list is its payload tensor itself -- with two ranks, every slot compared, issued from the helper thread and from the
+    calling thread"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 1000) + (7 if rotate else 0) + (13 if threaded else 0)
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, rotate, q, False, threaded)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(2))
+    assert res == {0: True, 1: True}
+
+
+def test_gather_pipe_fails_fast():
+    """the first exception of the helper thread ends the pipe -- no later gather is issued, and the owner's next
+    call raises instead of leaving its peers in a collective nobody matches"""
+    sys.path.insert(0, os.path.join(ROOT, "dark-archon_amd"))
+    import archon_shard
+
+    class Boom(RuntimeError):
+        pass
+
+    class FakeDist:
+        calls = 0
+
+        def gather(self, *a, **k):
+            FakeDist.calls += 1
+            raise Boom("gather failed")
+
+    pipe = archon_shard.GatherPipe(FakeDist(), 0, 2, 16, torch.device("cpu"), via_host=True)
+    pipe.next_buffer()
+    pipe.submit()                       # handed to the helper, which fails
+    with pytest.raises(Boom):
+        pipe.next_buffer()              # buffer 1: nothing pending, but the pipe is dead
+        pipe.submit()
+        pipe.next_buffer()
+    with pytest.raises(Boom):
+        pipe.submit()                   # raises at once, hands nothing over
+    assert FakeDist.calls == 1
+    with pytest.raises(Boom):
+        pipe.close()
+    assert pipe.queue is None           # the helper was stopped all the same
