@@ -877,7 +877,10 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // device, the whole streaming stage is queued behind it, and its kernels return at once when the flag says
     // "skewed".  One host round trip per block (after k_resolve_ties) instead of two.
     // bucket-per-workgroup pass B (Prep::aligned) needs 256 workgroups and enough tiles per bucket to matter
-    const uint32_t allow_aligned = (n >= (1u << 24) && !route_off(kRtNoAligned) && g_opt[c->dev].pass_b_buckets.load()) ? 1u : 0u;
+    const uint32_t aligned_min = g_route.aligned_min >= 0 ? (uint32_t)g_route.aligned_min : (1u << 24);      // (tests lower it to run bucket mode on small blocks)
+    const uint32_t allow_aligned = (n >= aligned_min && !route_off(kRtNoAligned) && g_opt[c->dev].pass_b_buckets.load()) ? 1u : 0u;
+    // bucket mode moves range-relative records between the passes (passes.hiph: no byte stream beside them)
+    const bool rel_ok = allow_aligned && !route_off(kRtNoRelRecords);
     int e1 = -1;
     // Clean periodic blocks (periodic.hiph): the period probe and the comparison of the whole text with itself p further down are
     // queued in FRONT of the count -- device-conditional, a block without a voted period pays three empty launches -- and their
@@ -946,28 +949,34 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         // (the tie summary was initialised on the device by k_rows_scan, which also left the count summary in it)
         constexpr int PB = bs::kPassBlock, PI = bs::kPassIPT;
         iA0 = ps.mark();
-        if (Q == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 2>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, key_text, d_skip, B.trash, &d_ctl->base_bucket);
-        else if (Q == 4)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 4>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, key_text, d_skip, B.trash, &d_ctl->base_bucket);
-        else if (Q == 8)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 8>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, key_text, d_skip, B.trash, &d_ctl->base_bucket);
-        else if (defer_big)      // periodic block: a few digits per tile
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 1, kHotRank>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, d_x, d_skip, B.trash, &d_ctl->base_bucket);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, 1>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, d_x, d_skip, B.trash, &d_ctl->base_bucket);
+        // Both record formats of the passes are queued (passes.hiph): the plain one and -- where bucket mode is possible at all -- the
+        // range-relative one; which of the two a block takes is the count's choice of pass-B mode (Prep::aligned), known on the device
+        // only, and the instantiation that does not match returns at once.
+        const uint32_t twin = rel_ok ? 1u : 0u;
+#define ARCHON_PASS_A(QQ, HOTF, KT) do { \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, QQ, HOTF, false>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, KT, d_skip, B.trash, &d_ctl->base_bucket, twin); \
+            if (rel_ok) { \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_text<PB, PI, QQ, HOTF, true>), dim3(R), dim3(PB), 0, s, d_x, n, tpr, A_R, A_B1, B.prep->startA, rhist, KT, d_skip, B.trash, &d_ctl->base_bucket, twin); \
+                ++c->launches; \
+            } } while (0)
+        if (Q == 2) ARCHON_PASS_A(2, false, key_text);
+        else if (Q == 4) ARCHON_PASS_A(4, false, key_text);
+        else if (Q == 8) ARCHON_PASS_A(8, false, key_text);
+        else if (defer_big) ARCHON_PASS_A(1, kHotRank, d_x);      // periodic block: a few digits per tile
+        else ARCHON_PASS_A(1, false, d_x);
+#undef ARCHON_PASS_A
         iA1 = ps.mark();
         // pass B walks the same tile grid in the same ranges; in bucket mode (Prep::aligned) workgroup c takes bucket c
         const uint32_t gridB = (allow_aligned && R < 256u) ? 256u : R;      // bucket mode needs 256; surplus workgroups return at once
         hipLaunchKernelGGL(bs::k_range_hist_text, dim3(R), dim3(bs::kRhBlock), 0, s, A_B1, n, tpr, rhist, 0u, kTileItems, d_skip);
-        hipLaunchKernelGGL(bs::k_col_prefix, dim3(256), dim3(1024), 0, s, rhist, R, d_skip);          // (harmless in bucket mode: the table is not read)
+        hipLaunchKernelGGL(bs::k_col_prefix, dim3(256), dim3(1024), 0, s, rhist, R, d_skip, twin);    // (bucket mode with range-relative records: pass A's table stays)
         iB0 = ps.mark();
-        if (defer_big)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<bs::kPassBBlock, bs::kPassBIPT, kHotRank>), dim3(gridB), dim3(bs::kPassBBlock), 0, s, A_R, A_B1, n, tpr, B_R,
-                               B.prep->startB, rhist, B.prep->startA, d_skip, B.prep->start16, B.trash);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<bs::kPassBBlock, bs::kPassBIPT>), dim3(gridB), dim3(bs::kPassBBlock), 0, s, A_R, A_B1, n, tpr, B_R,
-                               B.prep->startB, rhist, B.prep->startA, d_skip, B.prep->start16, B.trash);
+#define ARCHON_PASS_B(HOTF, RELF) hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_pass_rec<bs::kPassBBlock, bs::kPassBIPT, HOTF, RELF>), dim3(gridB), dim3(bs::kPassBBlock), 0, s, A_R, A_B1, n, tpr, B_R, \
+                                                     B.prep->startB, rhist, B.prep->startA, d_skip, B.prep->start16, B.trash, twin, rhist, R, tpr * kTileItems)
+        if (defer_big) { ARCHON_PASS_B(kHotRank, false); if (rel_ok) ARCHON_PASS_B(kHotRank, true); }
+        else { ARCHON_PASS_B(false, false); if (rel_ok) ARCHON_PASS_B(false, true); }
+        if (rel_ok) ++c->launches;
+#undef ARCHON_PASS_B
         iB1 = ps.mark();
         e2 = tm.mark();
         hipLaunchKernelGGL(bs::k_local_sort, dim3(65536), dim3(bs::kLsBlock), 0, s, B_R, B.prep->start16, n, sa,
@@ -2216,7 +2225,7 @@ int archon_hip_test_route(const char *name, long value)
         {"NO_PACK_STREAM", kRtNoPackStream}, {"NO_PAIR_CHAINS", kRtNoPairChains}, {"NO_PERIOD_HINT", kRtNoPeriodHint},
         {"NO_BREAK_ROUND", kRtNoBreakRound}, {"NO_PERIOD_PROBE", kRtNoPeriodProbe}, {"NO_PERIOD_STREAM", kRtNoPeriodStream}, {"NO_PROBE", kRtNoProbe},
         {"NO_RANK_WRITER", kRtNoRankWriter}, {"NO_TEXT_ROUNDS", kRtNoTextRounds}, {"NO_MID", kRtNoMid}, {"NO_SHALLOW", kRtNoShallow},
-        {"NO_CLOSED_FORM", kRtNoClosedForm},
+        {"NO_CLOSED_FORM", kRtNoClosedForm}, {"NO_REL_RECORDS", kRtNoRelRecords},
     };
     if (!strcmp(name, "RESET")) { g_route = Route(); return ARCHON_OK; }
     if (!strcmp(name, "FORCE_PATH")) { g_route.force_path = value < 0 ? -1 : (value ? 1 : 0); return ARCHON_OK; }
@@ -2226,6 +2235,7 @@ int archon_hip_test_route(const char *name, long value)
         return ARCHON_OK;
     }
     if (!strcmp(name, "SMALL_BLOCK")) { g_route.small_block = value; return ARCHON_OK; }
+    if (!strcmp(name, "ALIGNED_MIN")) { g_route.aligned_min = value; return ARCHON_OK; }
     if (!strcmp(name, "INV_ROWS")) { g_route.inv_rows = value < 0 ? -1 : value > 2 ? 1 : (int)value; return ARCHON_OK; }
     if (!strcmp(name, "INV_SLAB")) { g_route.inv_slab = value > 0 ? (uint32_t)value : 0u; return ARCHON_OK; }
     if (!strcmp(name, "INV_SBITS")) { g_route.inv_sbits = (int)value; return ARCHON_OK; }

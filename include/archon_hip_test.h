@@ -11,11 +11,12 @@
  *   FORCE_PATH   0 / 1 / -1   7-pass first stage / streaming first stage / the block decides
  *   PASS_RANGES  1..1024 / 0  ranges the streaming passes are cut into (0: one per CU)
  *   SMALL_BLOCK  bytes / -1   blocks below this size take the byte count + LSB passes instead of the streaming stage (-1: 8 MiB)
+ *   ALIGNED_MIN  bytes / -1   blocks from this size on may run pass B in bucket mode (-1: 16 MiB)
  *   INV_SLAB, INV_SBITS, INV_WALK_WGS   inverse: slab bytes per chain, log2 rows per chain head, walk workgroups per CU
  *   INV_ROWS                            inverse: 0 = every lane of the walk stores its own 16 bytes, 1 / 2 = slabs written by quads through
  *                                       128- / 64-byte rows of LDS, -1 = the product's rule (rows above 128 MiB)
  *   NO_ALIGNED NO_BREAK_ROUND NO_CHAINS NO_DEEP_HINT NO_PACK NO_PACK_STREAM NO_PAIR_CHAINS NO_PERIOD_HINT NO_PERIOD_PROBE
- *   NO_PERIOD_STREAM NO_PROBE NO_RANK_WRITER NO_TEXT_ROUNDS NO_MID NO_SHALLOW NO_CLOSED_FORM      nonzero switches the named step off
+ *   NO_PERIOD_STREAM NO_PROBE NO_RANK_WRITER NO_TEXT_ROUNDS NO_MID NO_SHALLOW NO_CLOSED_FORM NO_REL_RECORDS      nonzero switches the named step off
  * Returns 0, or ARCHON_E_ARG for an unknown name / a value out of range.  Process-wide; not thread-safe against
  * concurrent transforms (tests run one at a time).
  */

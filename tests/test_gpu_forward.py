@@ -51,6 +51,27 @@ def test_shapes_vs_oracle(archon, oracle, shape, n):
     assert archon.validate(x, sa)
 
 
+@pytest.mark.parametrize("records", ["relative", "plain"])
+@pytest.mark.parametrize("ranges", ["0", "77", "1024"])
+@pytest.mark.parametrize("shape,n", [("random", 1 << 20), ("random", (3 << 20) + 12345), ("dna", 1 << 21), ("random", 300007), ("text", 1 << 20)])
+def test_bucket_mode_record_formats(archon, oracle, shape, n, ranges, records, monkeypatch):
+    """pass B in bucket mode (a balanced block: workgroup c takes second-byte bucket c) on blocks the oracle finishes in seconds
+    (ALIGNED_MIN lowers the 16 MiB limit), with the range-relative records of passes.hiph -- the item of a record from its place
+    in the bucket and pass A's range table -- and with the plain ones (NO_REL_RECORDS), for pass A cut into 256 / 77 / 1024 ranges;
+    text is not balanced: the count turns bucket mode down on the device and the plain format's instantiations run"""
+    monkeypatch.setenv("ARCHON_ALIGNED_MIN", "65536")
+    monkeypatch.setenv("ARCHON_FORCE_PATH", "1")
+    if ranges != "0":
+        monkeypatch.setenv("ARCHON_PASS_RANGES", ranges)
+    if records == "plain":
+        monkeypatch.setenv("ARCHON_NO_REL_RECORDS", "1")
+    x = S.gen_shape(shape, n)
+    sa, bwt, base = archon.forward(x)
+    P, B, b0 = oracle.forward(x)
+    assert (sa == P).all() and (bwt == B).all() and base == b0
+    assert archon.stats()["path"] == 1
+
+
 def test_ff_heavy(archon, oracle):
     """0xFF runs exercise the end-of-string-above-255 rule (padding ties)."""
     rng = np.random.default_rng(5)

@@ -89,7 +89,8 @@ def test_hip_vs_reference_full_size(archon, case):
 
 @pytest.mark.parametrize("shape,route", [("random", "0"), ("dna", "0"), ("a", "0"), ("ab", "0"), ("random_copy", "0"),
                                          ("text", "1"), ("prose", "1"), ("motif", "1"), ("motif_defects", "1"),
-                                         ("a", "shortcut"), ("ab", "shortcut"), ("motif", "shortcut")])
+                                         ("a", "shortcut"), ("ab", "shortcut"), ("motif", "shortcut"),
+                                         ("random", "plain_records"), ("dna", "plain_records")])
 def test_hip_vs_reference_full_size_other_route(archon, shape, route, monkeypatch):
     """the full-size reference digests again with the first stage the block would NOT take by itself: the 7-pass route on
     the blocks that stream by themselves (ARCHON_FORCE_PATH=0: random, DNA on packed keys, the periodic ones, the block with a
@@ -99,6 +100,8 @@ def test_hip_vs_reference_full_size_other_route(archon, shape, route, monkeypatc
     case = [c for c in GOLDEN_FULL["cases"] if c["shape"] == shape and c["block"] == 0][0]
     if route == "shortcut":          # the clean periodic blocks without their closed form: a shallow first stage + the run shortcut
         monkeypatch.setenv("ARCHON_NO_CLOSED_FORM", "1")
+    elif route == "plain_records":   # bucket mode of pass B with the byte stream beside the records (by themselves these blocks take the range-relative ones)
+        monkeypatch.setenv("ARCHON_NO_REL_RECORDS", "1")
     else:
         monkeypatch.setenv("ARCHON_FORCE_PATH", route)
     n = case["n"]
@@ -109,6 +112,8 @@ def test_hip_vs_reference_full_size_other_route(archon, shape, route, monkeypatc
     st = archon.stats()
     if route == "shortcut":
         assert st["path"] != 2 and st["period"] in (1, 2, 1000) and st["doubling_rounds"] == 0
+    elif route == "plain_records":
+        assert st["path"] == 1
     else:
         assert st["path"] == int(route)
     assert _sha(out_t.cpu().numpy()) == case["sha256_bwt_base"]
