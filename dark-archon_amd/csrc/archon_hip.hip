@@ -107,6 +107,7 @@ int ctx_get(int dev, Ctx **out)
         memset(&c->stats, 0, sizeof c->stats);
         ARCHON_HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         ARCHON_HIP_TRY(hipHostMalloc((void **)&c->h_mail, Ctx::kMailWords * sizeof(uint32_t), hipHostMallocDefault));
+        ARCHON_HIP_TRY(hipHostGetDevicePointer((void **)&c->h_mail_dev, c->h_mail, 0));      // (coherent: bs::k_mail writes the block's summary there)
         ARCHON_HIP_TRY(hipMalloc((void **)&c->d_mail, Ctx::kMailWords * sizeof(uint32_t)));
         g_ctx[dev][slot] = c;
     }
@@ -990,14 +991,16 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
                            sa, d_bwt, 5u * (uint32_t)Q, 64u * (uint32_t)Q, d_skip);
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 7;
-        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_ctl, sizeof(bs::TieCtl), hipMemcpyDeviceToHost, s));
         // (on the chance that this is all the block needs -- the graded case -- the primary index goes to the caller and the
-        //  consistency flag to the host with the same round trip: the call then ends without a second one)
-        ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, &d_ctl->base_id, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-        ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 20, B.sc.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        //  consistency flag to the host with the same round trip: the call then ends without a second one.  Everything the host
+        //  reads -- summary, flag, byte counts for skewed blocks, the period probe -- is written into the pinned mailbox by k_mail.)
         e3 = tm.mark();
-        if (Q == 1) ARCHON_TRY(fetch_byte_counts());              // free with the round trip; used only by skewed blocks
-        ARCHON_TRY(fetch_probe());
+        static_assert(sizeof(bs::TieCtl) <= 20 * sizeof(uint32_t), "the summary in front of the flag's mailbox word");
+        hipLaunchKernelGGL(bs::k_mail, dim3(1), dim3(256), 0, s, d_ctl, B.sc.d_err, Q == 1 ? B.prep->cntA : nullptr, d_x + (n - 1),
+                           probe_queued ? pres : nullptr, c->h_mail_dev, d_base_out);
+        ARCHON_HIP_TRY(hipGetLastError());
+        ++c->launches;
+        if (Q == 1) have_byte_counts = true;                     // (used only by skewed blocks)
         ARCHON_HIP_TRY(hipStreamSynchronize(s));
         memcpy(&h_ctl, c->h_mail, sizeof h_ctl);
         big_items = h_ctl.big_items;
