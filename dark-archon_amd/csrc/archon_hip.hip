@@ -33,6 +33,7 @@ void set_error(const char *fmt, ...)
 }
 
 Route g_route;
+thread_local uint32_t t_sync_count = 0;
 
 // ------------------------------------------------------------------ contexts
 // Compute contexts of a device (arena, staging buffers, stream, mailbox each), created when first used: a host thread is
@@ -290,7 +291,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
     uint32_t *d_fu = B.small + 700;              // [0] entries appended to the next S list, [1] rank log entries, [2] the next B list, [3] its groups, [4] pairs listed, [5] pairs seen
     ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 4, d_fu, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     const uint32_t ms_first = ws_ready ? c->h_mail[4] : 0u, mb_first = c->h_mail[0], groups_first = c->h_mail[7];
     uint32_t m = ms_first + mb_first;
     st.unresolved_initial = m;
@@ -319,7 +320,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             ARCHON_HIP_TRY(hipMemsetAsync(tab, 0, 2 * fwd::kGapSlots * sizeof(uint32_t), s));
             hipLaunchKernelGGL(fwd::k_gap_sample, dim3(div_up(div_up(n, fwd::kGapStride), 256)), dim3(256), 0, s, sa, B.v, n, tab);
             ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, tab, 2 * fwd::kGapSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            ARCHON_HIP_TRY(hipStreamSynchronize(s));
+            ARCHON_SYNC(s);
             c->launches += 1;
             uint64_t total = 0;
             uint32_t best = 0;
@@ -350,7 +351,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             trace("chain_apply");
             ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 1, settled, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 2, d_lastbrk + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            ARCHON_HIP_TRY(hipStreamSynchronize(s));
+            ARCHON_SYNC(s);
             z_breaks = c->h_mail[2];
             c->launches += 8;
             if (c->h_mail[1] >= m) {
@@ -362,7 +363,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
                 hipLaunchKernelGGL(fwd::k_keep_flags, dim3(g256), dim3(256), 0, s, B.v, n, B.keep);
                 ARCHON_TRY(launch_scan<0>(s, B.keep, B.dst, n, B.scan_tmp, d_total));
                 ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                ARCHON_HIP_TRY(hipStreamSynchronize(s));
+                ARCHON_SYNC(s);
                 c->launches += 3;
                 m = c->h_mail[0];
             }
@@ -409,7 +410,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         ARCHON_HIP_TRY(hipGetLastError());
         c->launches += 2;
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_fu, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        ARCHON_SYNC(s);
         ms = c->h_mail[0];
         mb = c->h_mail[2];
         bgroups = mb / (fwd::kFuMax + 1u) + 2u;          // every group left in B is longer than kFuMax
@@ -469,7 +470,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
                                    (uint32_t)fwd::kMidSmallCap, (uint32_t)fwd::kMidLargeCap, (uint32_t)mid_dir_cap(n), B.sc.d_err, B.tile_big);
                 ARCHON_HIP_TRY(hipGetLastError());
                 ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 4200, B.mc, fwd::kMcWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                ARCHON_HIP_TRY(hipStreamSynchronize(s));
+                ARCHON_SYNC(s);
                 c->launches += 2;
                 if (c->h_mail[4200 + fwd::kMcGroups] > mid_dir_cap(n)) { set_error("B list of %u entries holds %u groups (directory: %zu)", mb, c->h_mail[4200], mid_dir_cap(n)); return ARCHON_E_INTERNAL; }
                 nS = c->h_mail[4200 + fwd::kMcSmall + cur];
@@ -573,7 +574,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         // written depends on how many there are, and the host has to wait for these counters anyway.
         if (mid) ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 4200, B.mc, fwd::kMcWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_fu, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        ARCHON_SYNC(s);
         const uint32_t nlog = mode != 1 ? c->h_mail[1] : 0u;
         // Rank updates, now that every key of the round has been read.  Dealt by item into windows of the table (rank_writer.hiph:
         // two partition sweeps + one window write, 0.6 ms whatever the number + 11 ps per update) they beat one random store each
@@ -617,7 +618,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
             ARCHON_HIP_TRY(hipGetLastError());
             c->launches += 4;
             ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, d_fu, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            ARCHON_HIP_TRY(hipStreamSynchronize(s));
+            ARCHON_SYNC(s);
             const uint32_t back = c->h_mail[0] - ms;         // entries the pass could not settle (two per pair)
             ms = c->h_mail[0];
             st.chain_pairs += np - back / 2u;
@@ -696,7 +697,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
                 ++st.break_rounds;
                 const bool distance = z_first;
 #ifdef ARCHON_EXPERIMENTS
-                ARCHON_HIP_TRY(hipStreamSynchronize(s));
+                ARCHON_SYNC(s);
                 const auto t0 = std::chrono::steady_clock::now();
                 const uint32_t ms0 = ms, mb0 = mb;
 #endif
@@ -723,7 +724,7 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
         st.unresolved_total += m;
         ++st.doubling_rounds;
 #ifdef ARCHON_EXPERIMENTS
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        ARCHON_SYNC(s);
         const auto t0 = std::chrono::steady_clock::now();
         const uint32_t ms0 = ms, mb0 = mb, mm0 = mm;
 #endif
@@ -761,6 +762,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     ARCHON_TRY(ctx_ensure_arena(c, forward_stage1_bytes(n, c->dev, d_sa_user == nullptr)));
     c->arena_reset();
     c->launches = 0;
+    if (depth == 0) t_sync_count = 0;
     archon_hip_stats &st = c->stats;
     memset(&st, 0, sizeof st);
     st.n = n;
@@ -1001,7 +1003,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ARCHON_HIP_TRY(hipGetLastError());
         ++c->launches;
         if (Q == 1) have_byte_counts = true;                     // (used only by skewed blocks)
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        ARCHON_SYNC(s);
         memcpy(&h_ctl, c->h_mail, sizeof h_ctl);
         big_items = h_ctl.big_items;
         if (h_ctl.fault) { set_error("tie list names rows outside the block (device flag 0x%x)", h_ctl.fault); return ARCHON_E_INTERNAL; }
@@ -1011,7 +1013,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 64, &B.prep->big_items, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         ARCHON_TRY(fetch_byte_counts());
         ARCHON_TRY(fetch_probe());
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        ARCHON_SYNC(s);
         big_items = c->h_mail[64];
         return ARCHON_OK;
     };
@@ -1059,7 +1061,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             ARCHON_TRY(fetch_probe());
             period_probed = true;
         }
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        ARCHON_SYNC(s);
         // (in the form the two-byte count leaves its column sums in -- the bytes x[0 .. n-2] and the 0xFF in front of x[0] --
         //  which is what the code below undoes)
         c->h_mail[128 + (c->h_mail[512] & 0xFFu)] -= 1u;
@@ -1110,7 +1112,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ARCHON_HIP_TRY(hipGetLastError());
         const int e_end = tm.mark();
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, off + m2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        ARCHON_SYNC(s);
         if (c->h_mail[0] != n) { set_error("closed form: the classes of period %u hold %u rows of %u", p, c->h_mail[0], n); return ARCHON_E_INTERNAL; }
         memset(&st, 0, sizeof st);
         st.n = n;
@@ -1122,6 +1124,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         st.ms_hist = tm.ms(e0, e1);
         st.ms_sort = tm.ms(e1, e_end);
         st.ms_total = tm.ms(e0, e_end);
+        st.host_syncs = t_sync_count;
         return ARCHON_OK;
     }
     constexpr uint32_t kPackSigma = 32;          // alphabets up to this many distinct bytes sort on packed keys
@@ -1134,7 +1137,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         // alphabet from a presence map; a block that only LOOKED poor is counted again without the probe
         hipLaunchKernelGGL(bs::k_presence, dim3(kNumCU * 8), dim3(256), 0, s, d_x, n, B.prep->present);
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 520, B.prep->present, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        ARCHON_SYNC(s);
         ++c->launches;
         for (uint32_t v = 0; v < 256; ++v) {
             h_lut[v] = (uint8_t)sigma;
@@ -1165,7 +1168,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             hipLaunchKernelGGL(fwd::k_period_find, dim3(fwd::kPeriodSearch / 256), dim3(256), 0, s, d_x, n, pres);
             hipLaunchKernelGGL(fwd::k_period_vote, dim3(fwd::kPeriodVotes / 256), dim3(256), 0, s, d_x, n, pres);
             ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, pres, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            ARCHON_HIP_TRY(hipStreamSynchronize(s));
+            ARCHON_SYNC(s);
             c->launches += 2;
         }
         if (c->h_mail[0] != 0xFFFFFFFFu && c->h_mail[1] * 10 >= fwd::kPeriodVotes * 9) {
@@ -1199,7 +1202,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         hipLaunchKernelGGL(fwd::k_period_breaks, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, n, period_hint, B.brk, d_lastbrk);
         ARCHON_TRY(launch_scan<1>(s, B.brk, B.brk, n, B.scan_tmp, nullptr));
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 2, d_lastbrk + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        ARCHON_SYNC(s);
         c->launches += 4;
         brk_ready = true;
         period_breaks = route_off(kRtNoBreakRound) ? 0u : c->h_mail[2];
@@ -1238,7 +1241,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
                     st.alphabet_bits = 8 / q;
                 }
             }
-            ARCHON_HIP_TRY(hipStreamSynchronize(s));          // the table upload has left h_mail
+            ARCHON_SYNC(s);          // the table upload has left h_mail
         }
     }
     st.path = (uint32_t)path;
@@ -1307,7 +1310,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
                 }
                 if (!tail_fetched) {
                     ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 520, d_x + (n - 8), 8, hipMemcpyDeviceToHost, s));
-                    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+                    ARCHON_SYNC(s);
                 }
                 const uint8_t *tail = reinterpret_cast<const uint8_t *>(c->h_mail + 520);      // x[n-8 .. n-1]
                 for (uint32_t q = 1; q <= 7; ++q) {
@@ -1357,7 +1360,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     } else {
         e5 = tm.mark();
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, B.sc.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        ARCHON_SYNC(s);
         dev_err = c->h_mail[0];
     }
     if (dev_err) {
@@ -1370,6 +1373,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     st.ms_bwt = need_general ? tm.ms(e4, e5) : 0.f;
     st.ms_total = tm.ms(e0, e5);
     st.kernel_launches = c->launches;
+    st.host_syncs = t_sync_count;
     for (int i = 0; i + 1 < pt.n; i += 2) {      // 7-pass route: rs::sort_pairs brackets each pass
         st.ms_radix_pass_sum += pt.ms(i, i + 1);
         ++st.radix_pass_timed;
@@ -1440,7 +1444,7 @@ int archon_hip_forward(const uint8_t *x, uint32_t n, uint32_t *sa_or_null, uint8
     ARCHON_HIP_TRY(hipMemcpyAsync(bwt, d_bwt, n, hipMemcpyDeviceToHost, s));
     ARCHON_HIP_TRY(hipMemcpyAsync(base_id, d_base, 4, hipMemcpyDeviceToHost, s));
     if (sa_or_null) ARCHON_HIP_TRY(hipMemcpyAsync(sa_or_null, d_sa, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     return ARCHON_OK;
 }
 
@@ -1534,7 +1538,7 @@ int archon_hip_block_forward(archon_hip_block *b, const uint8_t *x, uint32_t n, 
     ARCHON_TRY(forward_run(c, s, b->d_x, n, d_sa, b->d_bwt, d_base));
     ARCHON_HIP_TRY(hipMemcpyAsync(base_id, d_base, 4, hipMemcpyDeviceToHost, s));
     if (sa_or_null) ARCHON_HIP_TRY(hipMemcpyAsync(sa_or_null, d_sa, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     b->n = n;
     b->base = *base_id;
     b->has_sa = sa_or_null != nullptr;
@@ -1691,7 +1695,7 @@ int archon_hip_inverse(const uint8_t *bwt, uint32_t n, uint32_t base_id, uint8_t
     ARCHON_HIP_TRY(hipMemcpyAsync(d_in, bwt, n, hipMemcpyHostToDevice, s));
     ARCHON_TRY(keep_stats(c, inverse_run(c, s, d_in, n, base_id, d_out)));
     ARCHON_HIP_TRY(hipMemcpyAsync(x_out, d_out, n, hipMemcpyDeviceToHost, s));
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     return ARCHON_OK;
 }
 
@@ -1704,7 +1708,7 @@ int archon_hip_hist256_dev(const uint8_t *d_x, size_t n, uint32_t *d_out256, int
     ARCHON_HIP_TRY(hipSetDevice(dev));
     hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
     ARCHON_TRY(launch_hist256(s, d_x, n, d_out256, n));
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     return ARCHON_OK;
 }
 
@@ -1778,13 +1782,13 @@ static int sa_to_bwt_run(Ctx *c, hipStream_t s, const uint8_t *d_x, uint32_t n, 
     hipLaunchKernelGGL(fwd::k_sa_to_bwt, dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, s, d_x, d_sa, n, d_bwt, res + 2, res);
     ARCHON_HIP_TRY(hipGetLastError());
     ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, res, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     if (c->h_mail[0] || c->h_mail[1] != 1) {
         set_error("not a suffix array in a7 order: %s", c->h_mail[0] ? "values outside 1..n" : "no single row holds n");
         return ARCHON_E_CORRUPT;
     }
     ARCHON_HIP_TRY(hipMemcpyAsync(d_base_out, res + 2, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     return ARCHON_OK;
 }
 
@@ -1820,7 +1824,7 @@ int archon_hip_sa_to_bwt(const uint8_t *x, uint32_t n, const uint32_t *sa, uint8
     ARCHON_TRY(sa_to_bwt_run(c, s, d_x, n, d_sa, d_bwt, c->d_mail + 610));
     ARCHON_HIP_TRY(hipMemcpyAsync(bwt, d_bwt, n, hipMemcpyDeviceToHost, s));
     ARCHON_HIP_TRY(hipMemcpyAsync(base_id, c->d_mail + 610, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     return ARCHON_OK;
 }
 
@@ -1830,7 +1834,7 @@ static int post_run(Ctx *c, hipStream_t s, const uint8_t *d_bwt, uint32_t n, uin
     const uint32_t np = post::pieces_of(n);
     if (np == 0) {                                   // an empty block: u32 pieces = 0
         ARCHON_HIP_TRY(hipMemsetAsync(d_out, 0, 4, s));
-        ARCHON_HIP_TRY(hipStreamSynchronize(s));
+        ARCHON_SYNC(s);
         *out_bytes = 4;
         return ARCHON_OK;
     }
@@ -1844,7 +1848,7 @@ static int post_run(Ctx *c, hipStream_t s, const uint8_t *d_bwt, uint32_t n, uin
     hipLaunchKernelGGL(post::k_post_gather, dim3(np), dim3(256), 0, s, slots, sizes, np, d_out, d_total);
     ARCHON_HIP_TRY(hipGetLastError());
     ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 630, d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     unsigned long long total;
     memcpy(&total, c->h_mail + 630, sizeof total);
     if (total < 4 + 4ull * np || total > post::block_bound(n)) { set_error("post stage: stream length %llu out of bounds", total); return ARCHON_E_INTERNAL; }
@@ -1867,7 +1871,7 @@ static int post_decode_run(Ctx *c, hipStream_t s, const uint8_t *d_in, size_t in
     hipLaunchKernelGGL(post::k_post_decode, dim3(div_up(np_max, post::kDecWaves)), dim3(64 * post::kDecWaves), 0, s, d_in, off, meta, d_bwt, meta + 2);
     ARCHON_HIP_TRY(hipGetLastError());
     ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 640, meta, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     c->launches += 2;
     if (c->h_mail[642]) { set_error("post stage: malformed stream (flag 0x%x)", c->h_mail[642]); return ARCHON_E_CORRUPT; }
     *n_out = c->h_mail[640];
@@ -1906,7 +1910,7 @@ int archon_hip_inverse_post(const uint8_t *in, size_t in_bytes, uint32_t base_id
     if (base_id >= n) { set_error("base_id %u >= n %u", base_id, n); return ARCHON_E_ARG; }
     ARCHON_TRY(keep_stats(c, inverse_run(c, s, d_bwt, n, base_id, d_out)));
     ARCHON_HIP_TRY(hipMemcpyAsync(x_out, d_out, n, hipMemcpyDeviceToHost, s));
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     return ARCHON_OK;
 }
 
@@ -1948,7 +1952,7 @@ int archon_hip_forward_post(const uint8_t *x, uint32_t n, uint8_t *out, size_t c
     // only the packed stream crosses the link
     ARCHON_HIP_TRY(hipMemcpyAsync(out, d_pk, *out_bytes, hipMemcpyDeviceToHost, s));
     ARCHON_HIP_TRY(hipMemcpyAsync(base_id, d_base, 4, hipMemcpyDeviceToHost, s));
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     return ARCHON_OK;
 }
 
@@ -1976,7 +1980,7 @@ static int lms_select_run(Ctx *c, hipStream_t s, const uint8_t *d_x, uint32_t n,
     hipLaunchKernelGGL(fwd::k_lms_flag, dim3(g256), dim3(256), 0, s, d_x, n, v, flag);
     ARCHON_TRY(launch_scan<0>(s, flag, dst, n, scan_tmp, small + 600));
     ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail, small + 600, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     const uint32_t n1 = c->h_mail[0];
     *n1_out = n1;
     ARCHON_HIP_TRY(hipMemsetAsync(d_count, 0, 256 * sizeof(uint32_t), s));
@@ -1994,7 +1998,7 @@ static int lms_select_run(Ctx *c, hipStream_t s, const uint8_t *d_x, uint32_t n,
         hipLaunchKernelGGL(fwd::k_lms_place, dim3(div_up(n1, 256)), dim3(256), 0, s, in_b ? kB : kA, in_b ? vB : vA, n1, small, d_items);
         ARCHON_HIP_TRY(hipGetLastError());
     }
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     return ARCHON_OK;
 }
 
@@ -2027,7 +2031,7 @@ int archon_hip_lms_select(const uint8_t *x, uint32_t n, uint32_t count[256], uin
     ARCHON_TRY(lms_select_run(c, s, d_x, n, c->d_mail + 1024, d_items, n1));
     ARCHON_HIP_TRY(hipMemcpyAsync(count, c->d_mail + 1024, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (*n1) ARCHON_HIP_TRY(hipMemcpyAsync(items, d_items, (size_t)*n1 * 4, hipMemcpyDeviceToHost, s));
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     return ARCHON_OK;
 }
 
@@ -2047,7 +2051,7 @@ int archon_hip_radix_scatter_dev(const uint8_t *d_src, size_t n, uint8_t *d_dst,
     if (grid > (uint32_t)kNumCU * 8) grid = kNumCU * 8;
     hipLaunchKernelGGL(k_fill_runs, dim3(grid), dim3(256), 0, s, d_starts, d_dst, n);
     ARCHON_HIP_TRY(hipGetLastError());
-    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+    ARCHON_SYNC(s);
     return ARCHON_OK;
 }
 

@@ -51,6 +51,7 @@ class Stats(ctypes.Structure):
         ("chain_items", ctypes.c_uint32), ("text_rounds", ctypes.c_uint32), ("seg_big_items", ctypes.c_uint64),
         ("chain_pairs", ctypes.c_uint64), ("break_rounds", ctypes.c_uint32), ("break_settled", ctypes.c_uint32),
         ("mid_items", ctypes.c_uint64), ("arena_bytes", ctypes.c_uint64),
+        ("host_syncs", ctypes.c_uint32), ("_pad2", ctypes.c_uint32),
     ]
 
     def asdict(self):

@@ -246,6 +246,8 @@ typedef struct archon_hip_stats {
     uint32_t break_settled;      /* rows such a round settled */
     uint64_t mid_items;          /* sum over rounds of entries in groups of 1025 .. 16384 rows, each sorted by one workgroup in LDS */
     uint64_t arena_bytes;        /* device workspace the call used (bump-allocated from the context's arenas; forward calls) */
+    uint32_t host_syncs;         /* times the host waited for the stream inside the call (forward calls: one for a block the streaming stage settles) */
+    uint32_t reserved0;
 } archon_hip_stats;
 
 int archon_hip_get_stats(int dev, archon_hip_stats *out);
