@@ -259,7 +259,23 @@ int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out)
             if (post && gpu_post) {
                 // the packed stream as it is: the worker's GPU decodes it (csrc/post.hiph) in front of the inverse transform
                 uint32_t sz = 0;
-                if (fread(&sz, 4, 1, fi) != 1 || sz < 4 || sz > in_cap) { p.fail(-2); return; }
+                if (fread(&sz, 4, 1, fi) != 1 || sz < 4 || sz > 4 + ((size_t)bsize / kPiece + 1) * (4 + archon_post_bound(kPiece))) { p.fail(-2); return; }
+                if (sz > in_cap) {
+                    // a stream longer than the pinned slot (the format allows up to 2.5 n, this build's encoder stops at 1.25 n): undone on
+                    // the host, the worker then runs the plain inverse on the slot (packed = 0)
+                    std::vector<byte> packed(sz);
+                    if (fread(packed.data(), 1, sz, fi) != sz || fread(&s->base, 4, 1, fi) != 1) { p.fail(-2); return; }
+                    const long n = post_unpack(packed.data(), sz, s->in, bsize, kPiece);
+                    if (n < 0) { p.fail(-2); return; }
+                    s->n = (size_t)n;
+                    s->packed = 0;
+                    s->last = s->n < bsize;
+                    if (s->n && s->base >= s->n) { p.fail(-2); return; }
+                    const bool last = s->last;
+                    p.set(s, kFilled);
+                    if (last) { p.total(b + 1); return; }
+                    continue;
+                }
                 if (fread(s->in, 1, sz, fi) != sz || fread(&s->base, 4, 1, fi) != 1) { p.fail(-2); return; }
                 s->packed = sz;
                 uint32_t np = 0;
@@ -274,7 +290,7 @@ int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out)
                         size_t off = 4 + 4 * (size_t)np;
                         bool ok = off <= sz;
                         for (uint32_t k = 0; ok && k + 1 < np; ++k) { uint32_t ps; memcpy(&ps, s->in + 4 + 4 * k, 4); off += ps; ok = off + 4 <= sz; }
-                        if (!ok) { p.fail(-2); return; }
+                        if (!ok || off + 4 > sz) { p.fail(-2); return; }      // (the last piece's length word lies inside the stream, also when it is the only piece)
                         uint32_t ln; memcpy(&ln, s->in + off, 4);
                         s->last = (size_t)(np - 1) * kPiece + ln < bsize;
                     }
@@ -309,7 +325,7 @@ int archon_container_decode(FILE *fi, FILE *fo, int ndev, uint32_t *bsize_out)
         workers.emplace_back([&, w] {
             archon_hip_bind_context(w % ndev, w / ndev);
             worker_loop(p, w, kWorkersPerGpu * ndev, w % ndev, [gpu_post, bsize](Slot &s, int dev) {
-                if (gpu_post) {
+                if (gpu_post && s.packed) {
                     uint32_t n = 0;
                     const int rc = archon_hip_inverse_post(s.in, s.packed, s.base, s.out, bsize, &n, dev);
                     s.n = n;

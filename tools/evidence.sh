@@ -23,7 +23,7 @@ bash tools/pmc.sh $tag/pmc write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- 256 rand
 bash tools/pmc.sh $tag/pmc sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS -- 256 random 3 || exit 1
 bash tools/pmc.sh $tag/pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_SALU -- 256 random 3 || exit 1
 python3 tools/pmc_summary.py $out/pmc > $out/pmc_fetch_write.txt 2>&1
-python3 tools/pmc_traffic.py $out/pmc profiles/$tag/pmc_fetch_write.txt > $out/pmc_traffic.log 2>&1 && cp profiles/pmc_traffic.json $out/pmc_traffic.json
+python3 tools/pmc_traffic.py $out/pmc profiles/$tag/pmc_fetch_write.txt $out/pmc_traffic.json > $out/pmc_traffic.log 2>&1
 echo "pmc done"
 timeout -k 10 200 python3 tools/pcie_inclusive.py 256 2>/dev/null | tail -1 > $out/pcie_inclusive.json; cat $out/pcie_inclusive.json
 for sh in random dna text a ab motif prose motif_defects random_copy; do

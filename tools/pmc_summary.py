@@ -18,4 +18,4 @@ for cc in sorted(glob.glob(root + "/*/*/*_counter_collection.csv")):
     for name in agg:
         parts = ["%s=%.4g" % (c, sum(v) / len(v)) for c, v in agg[name].items()]
         d = dur.get(name)
-        print("  %-28s n=%d %s %s" % (name[:28], len(next(iter(agg[name].values()))), ("ms=%.3f" % (sum(d) / len(d))) if d else "", " ".join(parts)))
+        print("  %-56s n=%d %s %s" % (name[:56], len(next(iter(agg[name].values()))), ("ms=%.3f" % (sum(d) / len(d))) if d else "", " ".join(parts)))

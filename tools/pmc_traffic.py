@@ -1,6 +1,7 @@
-"""Build profiles/pmc_traffic.json from the rocprofv3 --pmc passes tools/evidence.sh collects.
+"""Build <tag dir>/pmc_traffic.json from the rocprofv3 --pmc passes tools/evidence.sh collects (bench.py reads the newest
+profiles/rNN_final/pmc_traffic.json for roofline.traffic).
 
-usage: tools/pmc_traffic.py <pmc dir (gpurun_out/<tag>/pmc)> <source label> [n] [shape]
+usage: tools/pmc_traffic.py <pmc dir (gpurun_out/<tag>/pmc)> <source label> <output json> [n] [shape]
 
 Per kernel of the streaming path: mean FETCH_SIZE and WRITE_SIZE per dispatch (KiB, separate passes) ->
 HBM bytes per launch = 2 x FETCH_SIZE (gfx950 tallies 128-byte read requests at 64 bytes, MI355X_MICROARCH.md
@@ -12,9 +13,9 @@ import json
 import os
 import sys
 
-root, source = sys.argv[1], sys.argv[2]
-n = int(sys.argv[3]) if len(sys.argv) > 3 else 268435456
-shape = sys.argv[4] if len(sys.argv) > 4 else "random"
+root, source, dest = sys.argv[1], sys.argv[2], sys.argv[3]
+n = int(sys.argv[4]) if len(sys.argv) > 4 else 268435456
+shape = sys.argv[5] if len(sys.argv) > 5 else "random"
 ALG = {"bs::k_pass_text": 5, "bs::k_pass_rec": 9, "bs::k_local_sort": 13, "bs::k_hist16": 1}
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for cc in glob.glob(root + "/*/*/*_counter_collection.csv"):
@@ -22,7 +23,6 @@ for cc in glob.glob(root + "/*/*/*_counter_collection.csv"):
         name = r["Kernel_Name"].split("(")[0].split("<")[0].replace("archon::", "").replace("void ", "").strip()
         if name in ALG and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             vals[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-dest = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_traffic.json")
 try:
     prev = json.load(open(dest))          # entries of other shapes / sizes / routes stay (each carries its own `source`)
 except Exception:
@@ -35,8 +35,11 @@ ent = {}
 for name, c in vals.items():
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         continue
-    f = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
-    w = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+    # (both record formats of a pass are queued and the one that does not match the block returns at once: dispatches that moved
+    #  less than a tenth of the kernel's largest are those empty twins, not samples)
+    live = lambda v: [a for a in v if a >= 0.1 * max(v)] if max(v) > 0 else v
+    f = sum(live(c["FETCH_SIZE"])) / len(live(c["FETCH_SIZE"]))
+    w = sum(live(c["WRITE_SIZE"])) / len(live(c["WRITE_SIZE"]))
     ent[name] = {"fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024),
                  "algorithmic_bytes_per_launch": ALG[name] * n, "source": source}
 out["path1_%s_%d" % (shape, n)] = ent
