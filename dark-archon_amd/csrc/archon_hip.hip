@@ -883,7 +883,11 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     const uint32_t aligned_min = g_route.aligned_min >= 0 ? (uint32_t)g_route.aligned_min : (1u << 24);      // (tests lower it to run bucket mode on small blocks)
     const uint32_t allow_aligned = (n >= aligned_min && !route_off(kRtNoAligned) && g_opt[c->dev].pass_b_buckets.load()) ? 1u : 0u;
     // bucket mode moves range-relative records between the passes (passes.hiph: no byte stream beside them)
-    const bool rel_ok = allow_aligned && !route_off(kRtNoRelRecords);
+    // -- where a bucket's segments (one per pass-A range: n / (256 R) places on average) are long enough that a wave's 1024 places
+    // nearly always lie inside one: from 4096 places on, i.e. 256 MiB with one range per CU.  Shorter segments make pass B look its
+    // records' ranges up one by one: 16 / 64 / 128 MiB blocks measured 0.36 / 0.46 / 0.62 ms in pass B against 0.08 / 0.25 / 0.52.
+    const uint32_t rel_min_seg = g_route.rel_min_seg >= 0 ? (uint32_t)g_route.rel_min_seg : 4096u;
+    const bool rel_ok = allow_aligned && !route_off(kRtNoRelRecords) && (uint64_t)n >= (uint64_t)R * 256u * rel_min_seg;
     int e1 = -1;
     // Clean periodic blocks (periodic.hiph): the period probe and the comparison of the whole text with itself p further down are
     // queued in FRONT of the count -- device-conditional, a block without a voted period pays three empty launches -- and their
@@ -2243,6 +2247,7 @@ int archon_hip_test_route(const char *name, long value)
     }
     if (!strcmp(name, "SMALL_BLOCK")) { g_route.small_block = value; return ARCHON_OK; }
     if (!strcmp(name, "ALIGNED_MIN")) { g_route.aligned_min = value; return ARCHON_OK; }
+    if (!strcmp(name, "REL_MIN_SEG")) { g_route.rel_min_seg = value; return ARCHON_OK; }
     if (!strcmp(name, "INV_ROWS")) { g_route.inv_rows = value < 0 ? -1 : value > 2 ? 1 : (int)value; return ARCHON_OK; }
     if (!strcmp(name, "INV_SLAB")) { g_route.inv_slab = value > 0 ? (uint32_t)value : 0u; return ARCHON_OK; }
     if (!strcmp(name, "INV_SBITS")) { g_route.inv_sbits = (int)value; return ARCHON_OK; }

@@ -12,6 +12,7 @@
  *   PASS_RANGES  1..1024 / 0  ranges the streaming passes are cut into (0: one per CU)
  *   SMALL_BLOCK  bytes / -1   blocks below this size take the byte count + LSB passes instead of the streaming stage (-1: 8 MiB)
  *   ALIGNED_MIN  bytes / -1   blocks from this size on may run pass B in bucket mode (-1: 16 MiB)
+ *   REL_MIN_SEG  places / -1  bucket mode moves range-relative records when a bucket's segments average at least this many places (-1: 4096)
  *   INV_SLAB, INV_SBITS, INV_WALK_WGS   inverse: slab bytes per chain, log2 rows per chain head, walk workgroups per CU
  *   INV_ROWS                            inverse: 0 = every lane of the walk stores its own 16 bytes, 1 / 2 = slabs written by quads through
  *                                       128- / 64-byte rows of LDS, -1 = the product's rule (rows above 128 MiB)

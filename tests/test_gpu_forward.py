@@ -60,6 +60,7 @@ def test_bucket_mode_record_formats(archon, oracle, shape, n, ranges, records, m
     in the bucket and pass A's range table -- and with the plain ones (NO_REL_RECORDS), for pass A cut into 256 / 77 / 1024 ranges;
     text is not balanced: the count turns bucket mode down on the device and the plain format's instantiations run"""
     monkeypatch.setenv("ARCHON_ALIGNED_MIN", "65536")
+    monkeypatch.setenv("ARCHON_REL_MIN_SEG", "1")
     monkeypatch.setenv("ARCHON_FORCE_PATH", "1")
     if ranges != "0":
         monkeypatch.setenv("ARCHON_PASS_RANGES", ranges)

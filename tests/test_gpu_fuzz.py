@@ -101,6 +101,7 @@ def test_fuzz_natural_route_streaming_machinery(archon, oracle, seed, monkeypatc
     """the same generator through the graded machinery (small-block rule off: the default of this suite), with bucket mode and its
     range-relative records allowed from 64 KiB on"""
     monkeypatch.setenv("ARCHON_ALIGNED_MIN", "65536")
+    monkeypatch.setenv("ARCHON_REL_MIN_SEG", "1")
     rng = np.random.default_rng(seed)
     for x in _natural_cases(rng, 12):
         P, B, b0 = oracle.forward(x)

@@ -1,10 +1,14 @@
 #!/bin/bash
 set -o pipefail
 export TMPDIR=/tmp
-out=gpurun_out/r05_fuzz; mkdir -p $out
+out=gpurun_out/r05_c14; mkdir -p $out
+timeout -k 10 400 python3 -m pytest tests/test_gpu_forward.py tests/test_gpu_fuzz.py tests/test_gpu_cli.py -m gpu -x -q -k "bucket_mode or streaming_machinery or natural_route or container or post" > $out/tests_a.log 2>&1; rc=$?
+tail -2 $out/tests_a.log
+[ $rc = 0 ] || exit 1
+for mib in 16 64 128 256; do
+  timeout -k 10 120 python3 tools/stage_times.py $mib random 4 2>/dev/null | tail -1 | python3 -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('$mib MiB', d['ms_total'], d['ms_hist'], d['ms_pass_text'], d['ms_pass_rec'], d['ms_local_sort'], d['kernel_launches'])"
+done
 timeout -k 10 120 python3 tools/stage_times.py 256 random 3 inv 2>/dev/null | tail -1 | cut -c1-200
-timeout -k 10 300 python3 tools/fuzz_hunt.py 5000 5250 2>&1 | grep -v "^seed .* done" | tail -5 | tee $out/hunt.txt
-ARCHON_ALIGNED_MIN=65536 timeout -k 10 200 python3 tools/fuzz_hunt.py 5250 5400 2>&1 | grep -v "^seed .* done" | tail -3 | tee $out/hunt_bucket_mode.txt
-timeout -k 10 420 python3 tools/fuzz_big.py 600 660 2>&1 | tee $out/big_all.txt | grep -v "ok True" | tail -5 | tee $out/big.txt
-grep -c "ok True" $out/big_all.txt
-timeout -k 10 200 python3 tools/fuzz_defects.py 300 100 2>&1 | tail -2 | tee $out/defects.txt
