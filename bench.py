@@ -21,11 +21,18 @@ Rank 0 prints ONE JSON line with the contract fields plus
                 events recorded around each launch on the stream the library launches on
                 ("kernels" lists all three);
                 "traffic" = HBM bytes per launch from the committed rocprofv3 PMC passes
-                (profiles/pmc_traffic.json), null when no matching measurement is committed
+                (the newest profiles/rNN_final/pmc_traffic.json, named in "traffic_source"),
+                null when no matching measurement is committed
   cpu_baseline  the reference a7 (oracle/_ref/a7ref, built from /root/reference by
                 oracle/Makefile; kind "reference") or, when that binary is absent, the
-                repo's CPU oracle (kind "port"), single thread, on a bounded sample of
-                the same workload, rank 0 at N=1 only.
+                repo's CPU oracle (kind "port"): single thread, taskset-pinned to one core,
+                the WHOLE block of the metric (one stated run, about half a minute;
+                --cpu-sample-mib bounds it), rank 0 at N=1 only.
+and, at N = 1 behind the timed region (never part of `value`; --no-shapes skips them):
+  inverse       the graded block decoded again (A8 + A9): ms, MB/s, hops/s, fraction of the
+                B_inv = 17 roofline; output compared with the input
+  shapes        dna, a, ab, motif, text, prose at the same block size: one warm-up + best
+                of 3 each, gated by the reference's digests (tests/golden/golden_full.json)
 """
 import argparse
 import json
@@ -365,8 +372,8 @@ def main():
             # SURVEY.md 8(d)'s LSB-pass figures; the in-LDS bucket sort must read one 8-byte record and write 4 (SA) + 1
             # (BWT) bytes per item = 13 (in 8(d)'s pass-by-pass model it stands for passes 3..6 and sa_to_bwt, 42 B --
             # NOT used here: the fraction below prices only bytes the kernel itself has to move).
-            spec = [("bs::k_pass_text (LSB pass A: text -> 8-byte {key,index} records + symbol stream, 256-way by x[s-2])", "ms_pass_text", B_FIRST_PASS),
-                    ("bs::k_pass_rec (LSB pass B: stable 256-way bucketing of the records by x[s-1])", "ms_pass_rec", B_RADIX_PASS),
+            spec = [("bs::k_pass_text (LSB pass A: text -> 8-byte records {key, range-relative index | first key byte}, 256-way by x[s-2])", "ms_pass_text", B_FIRST_PASS),
+                    ("bs::k_pass_rec (LSB pass B: 256-way bucketing of the records by x[s-1], one second-byte bucket per workgroup)", "ms_pass_rec", B_RADIX_PASS),
                     ("bs::k_local_sort (one workgroup per 16-bit bucket: in-LDS sort of the remaining key bytes, SA + BWT out)", "ms_local_sort", B_LOCAL_SORT)]
             kernels = []
             for nm, key, bpi in spec:
