@@ -108,6 +108,7 @@ int ctx_get(int dev, Ctx **out)
         memset(&c->stats, 0, sizeof c->stats);
         ARCHON_HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         ARCHON_HIP_TRY(hipHostMalloc((void **)&c->h_mail, Ctx::kMailWords * sizeof(uint32_t), hipHostMallocDefault));
+        memset(c->h_mail, 0, Ctx::kMailWords * sizeof(uint32_t));
         ARCHON_HIP_TRY(hipHostGetDevicePointer((void **)&c->h_mail_dev, c->h_mail, 0));      // (coherent: bs::k_mail writes the block's summary there)
         ARCHON_HIP_TRY(hipMalloc((void **)&c->d_mail, Ctx::kMailWords * sizeof(uint32_t)));
         g_ctx[dev][slot] = c;
@@ -836,7 +837,11 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     uint32_t *d_base = small + 603;
     bs::TieCtl *d_ctl = reinterpret_cast<bs::TieCtl *>(small + 640);
     B.sc.h_mail = c->h_mail;
-    ARCHON_HIP_TRY(hipMemsetAsync(small, 0, 1024 * sizeof(uint32_t), s));
+    // (one launch clears the scratch words, arms the period probe's result word and clears the two-byte count's tables)
+    const size_t count_zero_bytes = (size_t)(reinterpret_cast<char *>(&B.prep->rowtot[0]) - reinterpret_cast<char *>(B.hist16));
+    hipLaunchKernelGGL(bs::k_prep, dim3(256), dim3(256), 0, s, small, 1024u, 610u, reinterpret_cast<uint4 *>(B.hist16), (uint32_t)(count_zero_bytes / 16));
+    static_assert(offsetof(bs::Prep, rowtot) % 16 == 0, "the count's tables end on a 16-byte boundary");
+    bool count_tables_clear = true;
 
     const uint8_t *d_x = d_x_in;
     if ((uintptr_t)d_x_in & 15) {   // kernels want 16-byte aligned text
@@ -897,7 +902,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     uint32_t *pres = small + 610;                // [0] period, [1] votes, [2] the text breaks it, [3] the whole text was compared
     bool probe_queued = false;
     auto queue_probe = [&]() -> int {
-        ARCHON_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)pres, (int)0xFFFFFFFFu, 1, s));      // (the votes and flags behind it are zero: `small` was cleared)
+        // (the result word was set to "none" and the votes and flags behind it cleared by k_prep)
         hipLaunchKernelGGL(fwd::k_period_find, dim3(fwd::kPeriodSearch / 256), dim3(256), 0, s, d_x, n, pres);
         hipLaunchKernelGGL(fwd::k_period_vote, dim3(fwd::kPeriodVotes / 256), dim3(256), 0, s, d_x, n, pres);
         c->launches += 2;
@@ -914,7 +919,8 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     };
     auto count16 = [&](int Q, const uint8_t *src, bool force_stream, bool probe = false, bool hot = false) -> int {
         uint32_t *d_suspect = probe ? &B.prep->suspect : nullptr;
-        ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, (size_t)(reinterpret_cast<char *>(&B.prep->rowtot[0]) - reinterpret_cast<char *>(B.hist16)), s));
+        if (!count_tables_clear) ARCHON_HIP_TRY(hipMemsetAsync(B.hist16, 0, count_zero_bytes, s));      // (the block's first count finds them cleared by k_prep)
+        count_tables_clear = false;
         // the count runs with at most 256 workgroups per half: with more pass ranges each workgroup covers several of
         // them and reads the column sums off between two (more workgroups would only flush their 32 768 bins more often)
         const uint32_t sub = (R > 256u && R % 256u == 0u) ? R / 256u : 1u;
@@ -1003,11 +1009,26 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         e3 = tm.mark();
         static_assert(sizeof(bs::TieCtl) <= 20 * sizeof(uint32_t), "the summary in front of the flag's mailbox word");
         hipLaunchKernelGGL(bs::k_mail, dim3(1), dim3(256), 0, s, d_ctl, B.sc.d_err, Q == 1 ? B.prep->cntA : nullptr, d_x + (n - 1),
-                           probe_queued ? pres : nullptr, c->h_mail_dev, d_base_out);
+                           probe_queued ? pres : nullptr, c->h_mail_dev, d_base_out, ++c->mail_seq);
         ARCHON_HIP_TRY(hipGetLastError());
         ++c->launches;
         if (Q == 1) have_byte_counts = true;                     // (used only by skewed blocks)
-        ARCHON_SYNC(s);
+        // the host's one wait of the block: spin on the sequence word k_mail writes last (pinned, coherent memory); should it not
+        // turn up within 50 ms the ordinary wait takes over (and reports whatever went wrong on the stream)
+        {
+            ++t_sync_count;
+            volatile uint32_t *seqw = c->h_mail + bs::kMailSeq;
+            const uint32_t want = c->mail_seq;
+            const auto t_spin = std::chrono::steady_clock::now();
+            for (uint32_t spins = 0; *seqw != want; ++spins) {
+                __builtin_ia32_pause();
+                if ((spins & 0xFFFu) == 0xFFFu && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(50)) {
+                    ARCHON_HIP_TRY(hipStreamSynchronize(s));
+                    break;
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
         memcpy(&h_ctl, c->h_mail, sizeof h_ctl);
         big_items = h_ctl.big_items;
         if (h_ctl.fault) { set_error("tie list names rows outside the block (device flag 0x%x)", h_ctl.fault); return ARCHON_E_INTERNAL; }
