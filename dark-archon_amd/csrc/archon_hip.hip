@@ -760,6 +760,15 @@ static int general_stage(Ctx *c, hipStream_t s, FwdBuf &B, const uint8_t *d_x, u
 static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n, uint32_t *d_sa_user,
                        uint8_t *d_bwt, uint32_t *d_base_out, int depth = 0)
 {
+#ifdef ARCHON_EXPERIMENTS
+    // host-side phases of a call (experiments library, ARCHON_TRACE_HOST): entry, first launch issued, everything queued, wait over, statistics read
+    static thread_local std::chrono::steady_clock::time_point t_host[5];
+    const bool trace_host = depth == 0 && getenv("ARCHON_TRACE_HOST") != nullptr;
+#define ARCHON_HOST_STAMP(i) do { if (trace_host) t_host[i] = std::chrono::steady_clock::now(); } while (0)
+#else
+#define ARCHON_HOST_STAMP(i) do { } while (0)
+#endif
+    ARCHON_HOST_STAMP(0);
     ARCHON_TRY(ctx_ensure_arena(c, forward_stage1_bytes(n, c->dev, d_sa_user == nullptr)));
     c->arena_reset();
     c->launches = 0;
@@ -842,6 +851,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     hipLaunchKernelGGL(bs::k_prep, dim3(256), dim3(256), 0, s, small, 1024u, 610u, reinterpret_cast<uint4 *>(B.hist16), (uint32_t)(count_zero_bytes / 16));
     static_assert(offsetof(bs::Prep, rowtot) % 16 == 0, "the count's tables end on a 16-byte boundary");
     bool count_tables_clear = true;
+    ARCHON_HOST_STAMP(1);
 
     const uint8_t *d_x = d_x_in;
     if ((uintptr_t)d_x_in & 15) {   // kernels want 16-byte aligned text
@@ -1013,6 +1023,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ARCHON_HIP_TRY(hipGetLastError());
         ++c->launches;
         if (Q == 1) have_byte_counts = true;                     // (used only by skewed blocks)
+        ARCHON_HOST_STAMP(2);
         // the host's one wait of the block: spin on the sequence word k_mail writes last (pinned, coherent memory); should it not
         // turn up within 50 ms the ordinary wait takes over (and reports whatever went wrong on the stream)
         {
@@ -1029,6 +1040,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
             }
             std::atomic_thread_fence(std::memory_order_acquire);
         }
+        ARCHON_HOST_STAMP(3);
         memcpy(&h_ctl, c->h_mail, sizeof h_ctl);
         big_items = h_ctl.big_items;
         if (h_ctl.fault) { set_error("tie list names rows outside the block (device flag 0x%x)", h_ctl.fault); return ARCHON_E_INTERNAL; }
@@ -1410,6 +1422,14 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         st.radix_pass_timed = 2;
     }
     (void)d_counts; (void)d_starts;
+    ARCHON_HOST_STAMP(4);
+#ifdef ARCHON_EXPERIMENTS
+    if (trace_host) {
+        auto us = [&](int a, int b) { return std::chrono::duration<double, std::micro>(t_host[b] - t_host[a]).count(); };
+        fprintf(stderr, "host phases: entry->first launch %.1f us, queue the rest %.1f us, wait %.1f us, statistics %.1f us (device %.1f us)\n",
+                us(0, 1), us(1, 2), us(2, 3), us(3, 4), st.ms_total * 1e3);
+    }
+#endif
     return ARCHON_OK;
 }
 
