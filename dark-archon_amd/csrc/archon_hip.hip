@@ -1028,6 +1028,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         // turn up within 50 ms the ordinary wait takes over (and reports whatever went wrong on the stream)
         {
             ++t_sync_count;
+            static_assert(bs::kMailSeq >= 4600 && bs::kMailSeq < Ctx::kMailWords, "the sequence word lies clear of every other use of the mailbox");
             volatile uint32_t *seqw = c->h_mail + bs::kMailSeq;
             const uint32_t want = c->mail_seq;
             const auto t_spin = std::chrono::steady_clock::now();

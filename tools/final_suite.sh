@@ -1,12 +1,24 @@
 #!/bin/bash
-# the round's last call: the whole -m gpu suite, then the inverse's evidence on the last library
+# the round's last call: bench lines of the last library (graded line with shapes / inverse / cpu_baseline, the same again, one rank
+# under torch.distributed.run), rocprofv3 kernel stats of the bench command, the inverse's kernels, then the whole -m gpu suite
 set -o pipefail
 export TMPDIR=/tmp
 out=gpurun_out/${1:-final}; mkdir -p $out
-timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $out/tests_final.log 2>&1; rc=$?; echo "tests rc=$rc"
-tail -2 $out/tests_final.log
-[ $rc = 0 ] || exit 1
-bash tools/inv_kernels.sh 8 > $out/inverse_kernels.txt 2>&1; cat $out/inverse_kernels.txt | cut -c1-150
-for mib in 256 128 64 16 4; do
-  timeout -k 10 120 python3 tools/stage_times.py $mib random 3 inv 2>/dev/null | tail -1 | sed "s/^/inverse-random-${mib}MiB /" | tee -a $out/stage_times_inverse.txt | cut -c1-200
+timeout -k 10 400 python3 bench.py --steps 20 --warmup 2 > $out/bench_line.json 2> $out/bench.err || exit 1
+echo "bench done"
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 2 --no-cpu-baseline 2> $out/bench_w1.err | tail -1 > $out/bench_line_torchrun_world1.json || exit 1
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-shapes > $out/bench_line_same_box_again.json 2>> $out/bench.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-shapes > $out/stats.log 2>&1 || exit 1
+cp $(ls $out/stats/*/*_kernel_stats.csv | tail -1) $out/kernel_stats.csv
+echo "stats done"
+for sh in random dna text a ab motif prose motif_defects random_copy; do
+  timeout -k 10 120 python3 tools/stage_times.py 256 $sh 3 2>/dev/null | tail -1 | sed "s/^/$sh /" >> $out/stage_times.txt || exit 1
 done
+timeout -k 10 120 python3 tools/stage_times.py 256 random 3 inv 2>/dev/null | tail -1 | sed "s/^/inverse-random /" >> $out/stage_times.txt
+for mib in 4 16 64 128; do
+  timeout -k 10 120 python3 tools/stage_times.py $mib random 3 2>/dev/null | tail -1 | sed "s/^/forward-random-${mib}MiB /" >> $out/stage_times.txt
+  timeout -k 10 120 python3 tools/stage_times.py $mib random 3 inv 2>/dev/null | tail -1 | sed "s/^/inverse-random-${mib}MiB /" >> $out/stage_times.txt
+done
+echo "stage times done"
+timeout -k 10 700 python3 -m pytest tests -m gpu -x -q > $out/tests_final.log 2>&1; rc=$?; echo "tests rc=$rc"
+tail -2 $out/tests_final.log
