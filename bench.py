@@ -214,8 +214,8 @@ def inverse_leg(bwt_t, base, x_t):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)       # (the first steps behind a cold start run 4 % slower: clocks, first touch of the arena)
     ap.add_argument("--block-mib", type=int, default=256, help="block size per GPU (BASELINE config: 256)")
     ap.add_argument("--shape", default="random", help="random|dna|text|a|ab|motif (graded config: random)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
