@@ -147,8 +147,8 @@ def pmc_traffic(path, n, shape, kname):
     return None, None
 
 
-PATH_NAMES = {0: "7 LSB passes on packed keys + refinement rounds", 1: "streaming (hist16, 2 LSB passes, in-LDS bucket sort)",
-              2: "closed form of a clean periodic block (sort of its first 2p bytes, expanded)"}
+PATH_NAMES = {0: "7 LSB passes + refinement rounds", 1: "streaming (hist16, 2 LSB passes, in-LDS bucket sort)",
+              2: "closed form (clean periodic block)"}
 EXTRA_SHAPES = ("dna", "a", "ab", "motif", "text", "prose")
 
 
@@ -372,9 +372,9 @@ def main():
             # SURVEY.md 8(d)'s LSB-pass figures; the in-LDS bucket sort must read one 8-byte record and write 4 (SA) + 1
             # (BWT) bytes per item = 13 (in 8(d)'s pass-by-pass model it stands for passes 3..6 and sa_to_bwt, 42 B --
             # NOT used here: the fraction below prices only bytes the kernel itself has to move).
-            spec = [("bs::k_pass_text (LSB pass A: text -> 8-byte records {key, range-relative index | first key byte}, 256-way by x[s-2])", "ms_pass_text", B_FIRST_PASS),
-                    ("bs::k_pass_rec (LSB pass B: 256-way bucketing of the records by x[s-1], one second-byte bucket per workgroup)", "ms_pass_rec", B_RADIX_PASS),
-                    ("bs::k_local_sort (one workgroup per 16-bit bucket: in-LDS sort of the remaining key bytes, SA + BWT out)", "ms_local_sort", B_LOCAL_SORT)]
+            spec = [("bs::k_pass_text (LSB pass A: text -> 8-byte records, 256-way by x[s-2])", "ms_pass_text", B_FIRST_PASS),
+                    ("bs::k_pass_rec (LSB pass B: records 256-way by x[s-1])", "ms_pass_rec", B_RADIX_PASS),
+                    ("bs::k_local_sort (in-LDS sort of a 16-bit bucket, SA + BWT out)", "ms_local_sort", B_LOCAL_SORT)]
             kernels = []
             for nm, key, bpi in spec:
                 t = float(np.mean([s[key] for s in stage]))
