@@ -11,6 +11,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "small_block_default: the test runs small blocks on the route the product takes by itself")
+    config.addinivalue_line("markers", "streaming_machinery: the test asserts statistics of the streaming stage on a small block: it keeps SMALL_BLOCK=0 "
+                            "also when the suite runs on the product's routes (ARCHON_TEST_PRODUCT_ROUTES=1)")
 
 
 @pytest.fixture(autouse=True)
@@ -19,7 +21,14 @@ def _streaming_stage_on_small_blocks(request, monkeypatch):
     stage -- the graded path -- is built for blocks that fill the chip.  The tests exist to exercise that machinery on
     inputs the oracle finishes in seconds, so by default they switch the small-block rule off (test route SMALL_BLOCK = 0);
     tests marked `small_block_default` (and everything that goes through bin/archon) run the product's own choice."""
-    if "small_block_default" not in request.keywords:
+    # ARCHON_TEST_PRODUCT_ROUTES=1 runs the suite a second time the other way round: every test takes the product's own small-block
+    # choice except those that assert the streaming machinery's statistics (marked `streaming_machinery`)
+    if os.environ.get("ARCHON_TEST_PRODUCT_ROUTES") == "1":
+        if "streaming_machinery" in request.keywords:
+            monkeypatch.setenv("ARCHON_SMALL_BLOCK", "0")
+        else:
+            monkeypatch.delenv("ARCHON_SMALL_BLOCK", raising=False)
+    elif "small_block_default" not in request.keywords:
         monkeypatch.setenv("ARCHON_SMALL_BLOCK", "0")
 
 

@@ -263,6 +263,7 @@ def test_long_repeats(archon, oracle, name, closed, monkeypatch):
     assert (bwt == B).all() and base == b0
 
 
+@pytest.mark.streaming_machinery
 @pytest.mark.parametrize("route", ["streaming", "lsb"])
 def test_long_repeats_use_the_shortcut(archon, monkeypatch, route):
     """periodic blocks without the closed form: two streaming passes + the run shortcut, or three LSB passes + the shortcut"""
@@ -570,6 +571,7 @@ def test_mid_groups_at_the_class_limits(archon, oracle, monkeypatch):
     assert st["mid_items"] > 0 and st["seg_big_items"] > 0
 
 
+@pytest.mark.streaming_machinery
 @pytest.mark.parametrize("sigma", [2, 3, 4, 5, 9, 16])
 @pytest.mark.parametrize("n", [70001, 1 << 20])
 def test_compacted_alphabet_streaming(archon, oracle, sigma, n):
@@ -592,6 +594,7 @@ def test_compacted_alphabet_streaming(archon, oracle, sigma, n):
     assert st["path"] == 1 and st["alphabet_bits"] == want_bits
 
 
+@pytest.mark.streaming_machinery
 def test_compacted_alphabet_with_repeats(archon, oracle):
     """small alphabet + repeated material: streaming stage on packed bytes, then oversize buckets / deep ties
     go to the doubling stage with the depth counted in symbols"""
@@ -688,6 +691,7 @@ def test_mid_sizes_lf_consistent(archon, shape, n):
     assert torch.equal(out_t, x_t)
 
 
+@pytest.mark.streaming_machinery
 @pytest.mark.parametrize("ranges", ["1024", "512", "300", "7"])
 def test_many_pass_ranges(archon, oracle, monkeypatch, ranges):
     """bench.py cuts the passes into 1024 ranges for N > 1 (shorter tails when RCCL holds CUs): prefix-summed range
