@@ -910,7 +910,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     const int forced = g_route.force_path;       // (tests): 0 = 7-pass route, 1 = streaming stage, -1 = the block decides
     const bool closed_ok = depth == 0 && forced < 0 && n >= (1u << 16) && !route_off(kRtNoPeriodProbe) && !route_off(kRtNoChains) && !route_off(kRtNoClosedForm);
     uint32_t *pres = small + 610;                // [0] period, [1] votes, [2] the text breaks it, [3] the whole text was compared
-    bool probe_queued = false;
+    bool probe_queued = false, probe_fetched = false;
     auto queue_probe = [&]() -> int {
         // (the result word was set to "none" and the votes and flags behind it cleared by k_prep)
         hipLaunchKernelGGL(fwd::k_period_find, dim3(fwd::kPeriodSearch / 256), dim3(256), 0, s, d_x, n, pres);
@@ -925,6 +925,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     };
     auto fetch_probe = [&]() -> int {            // (with the round trip that follows)
         if (probe_queued) ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 530, pres, pf::kCleanWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        probe_fetched = probe_queued;
         return ARCHON_OK;
     };
     auto count16 = [&](int Q, const uint8_t *src, bool force_stream, bool probe = false, bool hot = false) -> int {
@@ -1023,6 +1024,7 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ARCHON_HIP_TRY(hipGetLastError());
         ++c->launches;
         if (Q == 1) have_byte_counts = true;                     // (used only by skewed blocks)
+        probe_fetched = probe_queued;
         ARCHON_HOST_STAMP(2);
         // the host's one wait of the block: spin on the sequence word k_mail writes last (pinned, coherent memory); should it not
         // turn up within 50 ms the ordinary wait takes over (and reports whatever went wrong on the stream)
@@ -1081,7 +1083,18 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
     // the chip -- its two-byte count keeps 128 KiB of counters per workgroup on all 256 CUs, its bucket sort launches 65 536
     // workgroups -- and costs 0.7 ms whatever the block holds.  Below kSmallBlock a block takes a plain byte count and the LSB
     // passes, whose cost follows its size.
-    bool tail_fetched = false, period_probed = false;
+    bool tail_fetched = false, period_probed = false, hinted = false;
+    auto first_attempt = [&]() -> int {          // a big block: two-byte count (with the alphabet probe) and the streaming stage behind it
+        ARCHON_TRY(count16(1, d_x, forced == 1, probe));
+        if (forced == 0) {
+            ARCHON_TRY(count_wait());
+            path = 0;
+        } else {
+            ARCHON_TRY(streaming(1, d_x));
+            path = (forced == 1 || (uint64_t)big_items * 2 <= n) ? 1 : 0;
+        }
+        return ARCHON_OK;
+    };
     const uint32_t small_limit = g_route.small_block >= 0 ? (uint32_t)g_route.small_block : kSmallBlock;
     const bool small_block = forced < 0 && n >= 8 && n < small_limit;
     if (small_block) {
@@ -1111,16 +1124,12 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         ARCHON_TRY(queue_probe());
         period_probed = true;
     }
-    ARCHON_TRY(count16(1, d_x, forced == 1, probe));
-    if (forced == 0) {
-        ARCHON_TRY(count_wait());
-        path = 0;
-    } else {
-        ARCHON_TRY(streaming(1, d_x));
-        path = (forced == 1 || (uint64_t)big_items * 2 <= n) ? 1 : 0;
+    hinted = probe && c->hint_poor_alphabet;
+    if (!hinted) ARCHON_TRY(first_attempt());
     }
-    }
-    if (closed_ok && period_probed && c->h_mail[530] != 0xFFFFFFFFu && c->h_mail[533] == 1u && c->h_mail[532] == 0u) {
+    // returns ARCHON_OK when the block was written down in closed form, 1 when it is not a clean periodic block, < 0 on error
+    auto closed_form = [&]() -> int {
+        if (!(closed_ok && period_probed && probe_fetched && c->h_mail[530] != 0xFFFFFFFFu && c->h_mail[533] == 1u && c->h_mail[532] == 0u)) return 1;
         // ---- a clean periodic block (periodic.hiph): x[i] == x[i-p] for every i >= p (k_period_clean compared all of it), p minimal
         // (the smallest distance at which the block's middle window recurs: a smaller period would recur there too), n >= 16 p.
         // Sort the block's first 2p bytes -- the ordinary transform, nested -- and expand its suffix array.
@@ -1163,34 +1172,63 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
         st.ms_sort = tm.ms(e1, e_end);
         st.ms_total = tm.ms(e0, e_end);
         st.host_syncs = t_sync_count;
+        if (depth == 0) c->hint_poor_alphabet = true;      // (periodic after periodic: the probe's verdict before any count)
         return ARCHON_OK;
-    }
+    };
+    if (!hinted) { const int r = closed_form(); if (r <= 0) return r; }
     constexpr uint32_t kPackSigma = 32;          // alphabets up to this many distinct bytes sort on packed keys
     uint32_t sigma = 0, bits = 8;
     uint8_t *d_lut = reinterpret_cast<uint8_t *>(small + 900);
     uint8_t h_lut[256];
     bool have_lut = false;
-    if (probe && h_ctl.suspect) {
-        // a workgroup of the count saw at most 4 distinct bytes and the count was abandoned (k_hist16): get the exact
-        // alphabet from a presence map; a block that only LOOKED poor is counted again without the probe
+    bool presence_done = false;
+    auto presence = [&]() -> int {               // the exact alphabet: 256 presence bits -> sigma, h_lut (the order-preserving recode)
         hipLaunchKernelGGL(bs::k_presence, dim3(kNumCU * 8), dim3(256), 0, s, d_x, n, B.prep->present);
         ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 520, B.prep->present, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        if (!probe_fetched) ARCHON_TRY(fetch_probe());         // (hinted: the period probe's verdict has not travelled yet)
         ARCHON_SYNC(s);
         ++c->launches;
+        sigma = 0;
         for (uint32_t v = 0; v < 256; ++v) {
             h_lut[v] = (uint8_t)sigma;
             if ((c->h_mail[520 + (v >> 5)] >> (v & 31u)) & 1u) ++sigma;
         }
+        presence_done = true;
+        return ARCHON_OK;
+    };
+    if (hinted) {
+        // The last block of this context had at most 4 distinct bytes (DNA after DNA: BASELINE.json configs[3]), and its first
+        // attempt -- a count that gives up at once, the streaming stage queued behind it returning kernel by kernel, a round
+        // trip -- cost 160 us for nothing.  This one shows its alphabet first; with more than 4 distinct bytes it takes the
+        // ordinary first attempt after all, with 4 or fewer it goes where the count's probe would have sent it.
+        ARCHON_TRY(presence());
+        { const int r = closed_form(); if (r <= 0) return r; }
+        if (sigma <= 4) {
+            h_ctl.suspect = 1;
+            path = 0;
+        } else {
+            ARCHON_TRY(first_attempt());
+            { const int r = closed_form(); if (r <= 0) return r; }
+        }
+    }
+    if (probe && h_ctl.suspect) {
+        // a workgroup of the count saw at most 4 distinct bytes and the count was abandoned (k_hist16): get the exact
+        // alphabet from a presence map; a block that only LOOKED poor is counted again without the probe
+        if (!presence_done) ARCHON_TRY(presence());
         if (sigma <= 16 && !route_off(kRtNoPack)) {
             have_lut = true;
             path = 0;
         } else {
             sigma = 0;
+            h_ctl.suspect = 0;
             ARCHON_TRY(count16(1, d_x, false, false));
             ARCHON_TRY(streaming(1, d_x));
             path = ((uint64_t)big_items * 2 <= n) ? 1 : 0;
         }
+    } else {
+        sigma = 0;
     }
+    if (probe && !small_block) c->hint_poor_alphabet = have_lut && sigma <= 4;      // (what the next block of this context looks at first)
     // A periodic block (aaa..., abab..., a motif repeated: BASELINE.json configs[2]) needs no deep first stage: the run
     // shortcut of general_stage settles its chains whatever depth the first stage reached.  So it takes the streaming
     // passes after all -- two key bytes, its oversized buckets handed on as groups tied at depth 2 (k_unpack_big) --

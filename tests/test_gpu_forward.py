@@ -611,6 +611,41 @@ def test_compacted_alphabet_with_repeats(archon, oracle):
     assert st["path"] == 1 and st["alphabet_bits"] == 2 and st["doubling_rounds"] > 0
 
 
+@pytest.mark.streaming_machinery
+def test_alphabet_hint_between_blocks(archon, oracle):
+    """a context whose last block had <= 4 distinct bytes looks at the next block's alphabet before counting it (archon_hip.hip,
+    hint_poor_alphabet): the same order and the same route whatever block came before -- DNA after DNA, then blocks that break the
+    promise (256 symbols, 5 symbols, 4 symbols and one stray byte at the end), clean periodic blocks, DNA again"""
+    rng = np.random.default_rng(5)
+    n = (1 << 20) + 77
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    dna = lambda: acgt[rng.integers(0, 4, size=n)]
+    stray = dna()
+    stray[-3] = 0x80
+    blocks = [("dna", dna(), 1, 2), ("dna", dna(), 1, 2), ("random", rng.integers(0, 256, size=n, dtype=np.uint8), 1, 0),
+              ("dna", dna(), 1, 2), ("five", np.frombuffer(b"ACGTN", np.uint8)[rng.integers(0, 5, size=n)], 1, None),
+              ("dna", dna(), 1, 2), ("stray", stray, 1, None), ("dna", dna(), 1, 2), ("a", np.full(n, 65, np.uint8), 2, None),
+              ("dna", dna(), 1, 2), ("ab", np.tile(np.frombuffer(b"ab", np.uint8), n // 2 + 1)[:n].copy(), 2, None),
+              ("binary", acgt[rng.integers(0, 2, size=n)], 1, 1), ("dna", dna(), 1, 2)]
+    routes = {}
+    for name, x, path, bits in blocks:
+        x = np.ascontiguousarray(x)
+        sa, bwt, base = archon.forward(x)
+        st = archon.stats()
+        P, B, b0 = oracle.forward(x)
+        assert (sa == P).all() and (bwt == B).all() and base == b0, name
+        assert st["path"] == path and (bits is None or st["alphabet_bits"] == bits), (name, st)
+        routes.setdefault(name, []).append((st["path"], st["alphabet_bits"]))
+    assert len(set(routes["dna"])) == 1
+    # the second DNA block of a pair skips the count it would abandon
+    archon.forward(np.ascontiguousarray(blocks[2][1]))
+    x = np.ascontiguousarray(dna())
+    archon.forward(x)
+    first = archon.stats()["kernel_launches"]
+    archon.forward(x)
+    assert archon.stats()["kernel_launches"] < first
+
+
 @pytest.mark.parametrize("shape", ["random", "a"])
 def test_max_block(archon, shape):
     """the largest block the boundary accepts (MAX_N = 0x3FFFFF00 bytes, just under 1 GiB; the reference's own
