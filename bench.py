@@ -12,7 +12,13 @@ block b is seeded SEED_BASE+2+b), and for N>1 the per-block outputs BWT||baseId
 are gathered to rank 0 over RCCL (the path's one exchange step).
 The gather of step k is asynchronous (RCCL's own stream) and overlaps the sort of step k+1; the
 timed region ends only after every gather has completed.  Blocks are independent, per-GPU work is
-fixed: "scaling": "weak".
+fixed: "scaling": "weak".  A plain single-process run keeps TWO blocks in flight (--in-flight,
+config.blocks_in_flight): two feeder threads, each bound to its own compute context of the library
+(include/archon_hip.h: "two threads feeding one GPU"), take the K steps in turn -- every step is
+still one whole forward pass over one block, and the timed region is still exactly K of them; the
+same K steps then run once more one block at a time ("one_block_at_a_time"), and the per-kernel
+times of `roofline` are taken there (a kernel's elapsed time beside another block's kernels is not
+its own).  --in-flight 1 is the run of the earlier rounds.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline      the dominant kernel = whichever of the three streaming kernels (LSB pass A, LSB
@@ -205,10 +211,59 @@ def inverse_leg(bwt_t, base, x_t):
         if r and (best is None or dt < best):
             best, st = dt, pyarchon.stats(x_t.device.index or 0)
     same = bool(torch.equal(out_t, x_t))
+    # the walk's tail is latency (a few long chains): a second block in flight (two feeder threads with a context each) uses the
+    # chip meanwhile -- eight blocks, best of two runs, per block
+    outs = [torch.empty(n, dtype=torch.uint8, device=x_t.device) for _ in range(2)]
+    feeders = Feeders(2, x_t.device.index or 0)
+    body = lambda t, _k: pyarchon.inverse_dev(bwt_t, base, outs[t])
+    feeders.run(2, body)
+    torch.cuda.synchronize()
+    best2 = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        feeders.run(8, body)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 8
+        best2 = dt if best2 is None or dt < best2 else best2
+    feeders.close()
+    same = same and all(bool(torch.equal(o, x_t)) for o in outs)
     return {"ms": round(best * 1e3, 3), "MB_s": round(n / 1e6 / best, 1), "hops_per_s": round(n / best, 0),
             "frac_B17": round(17.0 * n / best / 1e9 / HBM_PEAK_GBS, 4), "ms_lf_build": round(st["ms_lf_build"], 3),
             "ms_lf_walk": round(st["ms_lf_walk"], 3), "chains": st["walk_chains"], "kernel_launches": st["kernel_launches"],
+            "two_blocks_in_flight": {"ms_per_block": round(best2 * 1e3, 3), "MB_s": round(n / 1e6 / best2, 1),
+                                     "frac_B17": round(17.0 * n / best2 / 1e9 / HBM_PEAK_GBS, 4)},
             "equals_input": same}, same
+
+
+class Feeders:
+    """F host threads, thread t bound to compute context t of the library on `dev_index` (include/archon_hip.h: a context = arena, stream,
+    mailbox; "two threads feeding one GPU") and launching on a stream of its own; run(count, body) deals steps 0..count-1 to them in turn
+    (step k -> thread k mod F, body(t, k)) and returns when all are done."""
+
+    def __init__(self, flight, dev_index):
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        self.flight, self.dev_index = flight, dev_index
+        self.tls = threading.local()
+        self.pool = ThreadPoolExecutor(flight)
+
+    def _feed(self, t, count, body):
+        import torch
+        import pyarchon
+        if not hasattr(self.tls, "stream"):
+            torch.cuda.set_device(self.dev_index)
+            pyarchon.bind_context(t, self.dev_index)
+            self.tls.stream = torch.cuda.Stream(device=torch.device("cuda", self.dev_index))
+        with torch.cuda.stream(self.tls.stream):
+            for k in range(t, count, self.flight):
+                body(t, k)
+
+    def run(self, count, body):
+        for f in [self.pool.submit(self._feed, t, count, body) for t in range(self.flight)]:
+            f.result()
+
+    def close(self):
+        self.pool.shutdown()
 
 
 def main():
@@ -222,6 +277,9 @@ def main():
     ap.add_argument("--cpu-sample-mib", type=int, default=1 << 20, help="bound the CPU baseline to the first so many MiB of the block (default: the whole block)")
     ap.add_argument("--no-shapes", action="store_true", help="skip the other named shapes and the inverse behind the timed region (N=1 runs them by default)")
     ap.add_argument("--no-sa", action="store_true", help="emit BWT only (the metric is quoted WITH the SA)")
+    ap.add_argument("--in-flight", type=int, default=0, help="blocks in flight per GPU: F host threads, each bound to its own compute context "
+                    "of the library (include/archon_hip.h: 'two threads feeding one GPU'), take the steps in turn (step k -> thread k mod F). "
+                    "0 = default: 2 for a plain single-process run, 1 under torch.distributed.run (there the gather of step k overlaps step k+1)")
     ap.add_argument("--gather-root", default="rotate", help="rotate (step k gathers on rank k mod N: no GPU takes in N-1 payloads "
                     "every step) | 0 (always rank 0)")
     ap.add_argument("--gather-threaded", type=int, default=1, help="1: the gather is issued from the pipe's helper thread (default) | 0: from "
@@ -286,6 +344,10 @@ def main():
     pass_ms, pass_cnt, stage = [], [], []
 
     host_trace = []
+    in_flight = args.in_flight if args.in_flight > 0 else (2 if (world == 1 and dist is None) else 1)
+    if dist is not None:
+        in_flight = 1            # (the gathers are collectives: every rank issues them in step order from one thread)
+    in_flight = max(1, min(in_flight, 4, args.steps))
 
     def step():
         t_a = time.perf_counter()
@@ -305,15 +367,67 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    del pass_ms[:], pass_cnt[:], stage[:], host_trace[:]
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    alone = None
+    if in_flight > 1:
+        # F blocks in flight: F feeder threads, thread t bound to compute context t of the library (its own arena, stream and mailbox), with
+        # its own SA and BWT||baseId buffers, takes steps t, t+F, t+2F, ...  Every step is still one whole forward pass over one block; what the
+        # second block buys is the chip's idle corners -- the tails of the first block's kernels (one workgroup per CU, the slowest CU sets the
+        # kernel's time) and its host round trip.  The same K steps run once more one block at a time behind the timed region: the per-kernel
+        # times of `roofline` come from THAT region (a kernel's elapsed time beside another block's kernels is not its own).
+        pyarchon.bind_context(0, local_rank)
+        sa_f = [sa_t] + [None if args.no_sa else torch.empty(n, dtype=torch.int32, device=dev) for _ in range(in_flight - 1)]
+        out_f = [torch.empty(n + 4, dtype=torch.uint8, device=dev) for _ in range(in_flight)]
+        stage_f = [[] for _ in range(in_flight)]
+        feeders = Feeders(in_flight, local_rank)
+
+        def one_step(t, _k):
+            pyarchon.forward_dev(x_t, sa_f[t], out_f[t][:n], out_f[t][n:].view(torch.int32))
+            stage_f[t].append(pyarchon.stats_raw(local_rank))
+
+        def run_steps(count):
+            feeders.run(count, one_step)
+
+        # (each thread warms its own context: its arena grows in its first step)
+        run_steps(args.warmup * in_flight)
+        for lst in stage_f:
+            del lst[:]
+        fence()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        fence()
+        dt = time.perf_counter() - t0
+        stage_flight = [s.asdict() for lst in stage_f for s in lst]
+        feeders.close()
+        # every thread's last block against the reference's digests (below: thread 0's through the ordinary gate)
+        flight_ok = True
+        ref_f = reference_digest(args.shape, my_block, n)
+        for t in range(1, in_flight):
+            if ref_f is not None and stage_f[t]:
+                flight_ok = flight_ok and sha256_of(out_f[t].cpu().numpy()) == ref_f["sha256_bwt_base"]
+                if sa_f[t] is not None:
+                    flight_ok = flight_ok and sha256_of(sa_f[t].cpu().numpy()) == ref_f["sha256_P"]
+        # ... and the same K steps one block at a time (the calling thread: context 0 again), for the kernels' own times
+        for _ in range(2):
+            step()
+        del stage[:], host_trace[:]
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt_alone = time.perf_counter() - t1
+        alone = {"ms_per_step": round(dt_alone * 1e3 / args.steps, 3), "MB_s": round(float(n) * args.steps / 1e6 / dt_alone, 1), "steps": args.steps}
+    else:
+        flight_ok = True
+        for _ in range(args.warmup):
+            step()
+        del pass_ms[:], pass_cnt[:], stage[:], host_trace[:]
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
     stage[:] = [s.asdict() for s in stage]
     pass_ms[:] = [s["ms_radix_pass_sum"] for s in stage]
     pass_cnt[:] = [s["radix_pass_timed"] for s in stage]
@@ -325,10 +439,13 @@ def main():
     # correctness gates on the timed output (after the timed region):
     #  (1) the rank's SA and BWT||baseId hashed against what THE REFERENCE produced for the same block
     #      (golden_full.json; every rank checks its own block), (2) LF-consistency of the SA on the device
-    ok = True
+    ok = flight_ok
     sha_ok = None
     ref = reference_digest(args.shape, my_block, n)
     own_last, gathered_last = pipe.last()
+    if in_flight > 1:
+        sha_first = sha256_of(out_f[0].cpu().numpy()) == ref["sha256_bwt_base"] if ref is not None else True
+        ok = ok and sha_first
     if ref is not None:
         sha_ok = sha256_of(own_last.cpu().numpy()) == ref["sha256_bwt_base"]
         if sa_t is not None:
@@ -417,6 +534,7 @@ def main():
                 "gates_passed": ok,                        # reference digests + LF-consistency (+ gathered round trip)
                 "gathered_block_round_trip": gathered_ok,
                 "pass_ranges": pass_ranges or 256,
+                "blocks_in_flight": in_flight,     # F feeder threads, one compute context each; a step is still one whole block
                 "backend": (dist.get_backend() if dist is not None else None),
                 "dist_world_size": (dist.get_world_size() if dist is not None else 1),
                 "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if dist is not None and args.backend == "nccl" else None),
@@ -435,9 +553,12 @@ def main():
                 "launches_per_step": per_step,
                 "algorithmic_bytes_per_launch": bpi_dom * n,
                 "kernels": kernels,
+                "measured_over": ("the %d steps run one block at a time behind the timed region (HIP events around each launch); with %d blocks "
+                                  "in flight a kernel's elapsed time includes the other block's kernels" % (args.steps, in_flight)) if in_flight > 1
+                                 else "the timed region (HIP events around each launch)",
             },
             "pipeline": {
-                "device_ms_per_block": round(dev_ms, 3),
+                "device_ms_per_block": round(dev_ms, 3),           # one block alone on the chip
                 "algorithmic_bytes_per_input_byte": B_FWD_CFG2,
                 "frac_of_hbm_roofline": round(B_FWD_CFG2 * n / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dev_ms > 0 else None,
                 "path": PATH_NAMES.get(last["path"], str(last["path"])),
@@ -454,6 +575,11 @@ def main():
                 "unresolved_initial": last["unresolved_initial"], "kernel_launches": last["kernel_launches"],
             },
         }
+        if alone is not None:
+            # the timed region's own fraction: 57 B x N / (wall time per block) / 8 TB/s; and the one-block-at-a-time region
+            line["pipeline"]["frac_of_hbm_roofline_in_flight"] = round(B_FWD_CFG2 * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            line["pipeline"]["device_ms_per_block_in_flight"] = round(float(np.mean([s["ms_total"] for s in stage_flight])), 3)
+            line["one_block_at_a_time"] = alone
         if world == 1 and dist is None and not args.no_shapes:
             # behind the timed region: the other named shapes at this block size and the inverse of the graded block, each gated
             inv, inv_ok = inverse_leg(own_last[:n], int(own_last[n:].view(torch.int32).item()), x_t)
