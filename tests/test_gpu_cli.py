@@ -150,6 +150,30 @@ def test_bench_two_rank_rehearsal():
     assert line["value"] > 0 and "roofline" in line and "cpu_baseline" not in line
 
 
+def test_bench_default_run_keeps_two_blocks_in_flight():
+    """the driver's N = 1 command at a small block: two feeder threads with a compute context each take the steps in turn, the same
+    steps then run one block at a time for the kernels' own times; every gate (LF consistency, the inverse, the other shapes -- at
+    sizes without a committed digest the digest gates report null) still passes.  Not a measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra, flight in (([], 2), (["--in-flight", "1"], 1), (["--in-flight", "3", "--no-sa"], 3)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1", "--block-mib", "16",
+                            "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=280, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["config"]["blocks_in_flight"] == flight and line["steps"] == 5 and line["n_gpus"] == 1
+        assert line["config"]["gates_passed"] is True and line["value"] > 0
+        assert ("one_block_at_a_time" in line) == (flight > 1)
+        if flight > 1:
+            assert "one block at a time" in line["roofline"]["measured_over"] and line["pipeline"]["frac_of_hbm_roofline_in_flight"] > 0
+        if "--no-sa" not in extra:
+            assert line["config"]["sa_lf_consistent"] is True
+        assert line["inverse"]["equals_input"] is True and line["inverse"]["two_blocks_in_flight"]["ms_per_block"] > 0
+        assert all(v["sa_sha256_matches_reference"] is not False for v in line["shapes"].values())
+
+
 def test_concurrent_host_threads(archon, oracle):
     """calls on one device from several host threads are serialised by the per-device mutex
     (ctypes releases the GIL during the call); every thread must get its own block's result."""
