@@ -12,13 +12,15 @@ block b is seeded SEED_BASE+2+b), and for N>1 the per-block outputs BWT||baseId
 are gathered to rank 0 over RCCL (the path's one exchange step).
 The gather of step k is asynchronous (RCCL's own stream) and overlaps the sort of step k+1; the
 timed region ends only after every gather has completed.  Blocks are independent, per-GPU work is
-fixed: "scaling": "weak".  A plain single-process run keeps TWO blocks in flight (--in-flight,
+fixed: "scaling": "weak".  Every rank keeps TWO blocks in flight (--in-flight,
 config.blocks_in_flight): two feeder threads, each bound to its own compute context of the library
 (include/archon_hip.h: "two threads feeding one GPU"), take the K steps in turn -- every step is
-still one whole forward pass over one block, and the timed region is still exactly K of them; the
-same K steps then run once more one block at a time ("one_block_at_a_time"), and the per-kernel
-times of `roofline` are taken there (a kernel's elapsed time beside another block's kernels is not
-its own).  --in-flight 1 is the run of the earlier rounds.
+still one whole forward pass over one block, and the timed region is still exactly K of them; for
+N>1 a feeder hands its step to the gather pipe only when every earlier step has been handed over
+(the collectives leave every rank in step order).  The same K steps then run once more one block
+at a time ("one_block_at_a_time"), and the per-kernel times of `roofline` are taken there (a
+kernel's elapsed time beside another block's kernels is not its own).  --in-flight 1 is the run
+of the earlier rounds.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline      the dominant kernel = whichever of the three streaming kernels (LSB pass A, LSB
@@ -240,10 +242,10 @@ class Feeders:
     mailbox; "two threads feeding one GPU") and launching on a stream of its own; run(count, body) deals steps 0..count-1 to them in turn
     (step k -> thread k mod F, body(t, k)) and returns when all are done."""
 
-    def __init__(self, flight, dev_index):
+    def __init__(self, flight, dev_index, on_error=None):
         import threading
         from concurrent.futures import ThreadPoolExecutor
-        self.flight, self.dev_index = flight, dev_index
+        self.flight, self.dev_index, self.on_error = flight, dev_index, on_error
         self.tls = threading.local()
         self.pool = ThreadPoolExecutor(flight)
 
@@ -254,9 +256,14 @@ class Feeders:
             torch.cuda.set_device(self.dev_index)
             pyarchon.bind_context(t, self.dev_index)
             self.tls.stream = torch.cuda.Stream(device=torch.device("cuda", self.dev_index))
-        with torch.cuda.stream(self.tls.stream):
-            for k in range(t, count, self.flight):
-                body(t, k)
+        try:
+            with torch.cuda.stream(self.tls.stream):
+                for k in range(t, count, self.flight):
+                    body(t, k)
+        except Exception as e:      # noqa: BLE001
+            if self.on_error is not None:
+                self.on_error(e)        # (the other feeders may be waiting for this one's step)
+            raise
 
     def run(self, count, body):
         for f in [self.pool.submit(self._feed, t, count, body) for t in range(self.flight)]:
@@ -279,7 +286,7 @@ def main():
     ap.add_argument("--no-sa", action="store_true", help="emit BWT only (the metric is quoted WITH the SA)")
     ap.add_argument("--in-flight", type=int, default=0, help="blocks in flight per GPU: F host threads, each bound to its own compute context "
                     "of the library (include/archon_hip.h: 'two threads feeding one GPU'), take the steps in turn (step k -> thread k mod F). "
-                    "0 = default: 2 for a plain single-process run, 1 under torch.distributed.run (there the gather of step k overlaps step k+1)")
+                    "0 = default: 2 (per rank, whatever N: the gathers of N > 1 are still issued in step order)")
     ap.add_argument("--gather-root", default="rotate", help="rotate (step k gathers on rank k mod N: no GPU takes in N-1 payloads "
                     "every step) | 0 (always rank 0)")
     ap.add_argument("--gather-threaded", type=int, default=1, help="1: the gather is issued from the pipe's helper thread (default) | 0: from "
@@ -324,8 +331,9 @@ def main():
     sa_t = None if args.no_sa else torch.empty(n, dtype=torch.int32, device=dev)
     # BWT || baseId (LE), double-buffered: the gather of step k runs on RCCL's stream while step k+1 sorts
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
+    in_flight = max(1, min(args.in_flight if args.in_flight > 0 else 2, 4, args.steps))
     pipe = archon_shard.GatherPipe(dist, rank, world, n + 4, dev, via_host=(args.backend != "nccl"), rotate=(args.gather_root == "rotate"),
-                                   threaded=bool(args.gather_threaded))
+                                   threaded=bool(args.gather_threaded), nbuf=2 * in_flight)
     pass_ranges = 0
     if world > 1:
         # RCCL's send/recv kernels hold CUs while the gather of step k overlaps the sort of step k+1, and a pass
@@ -344,10 +352,6 @@ def main():
     pass_ms, pass_cnt, stage = [], [], []
 
     host_trace = []
-    in_flight = args.in_flight if args.in_flight > 0 else (2 if (world == 1 and dist is None) else 1)
-    if dist is not None:
-        in_flight = 1            # (the gathers are collectives: every rank issues them in step order from one thread)
-    in_flight = max(1, min(in_flight, 4, args.steps))
 
     def step():
         t_a = time.perf_counter()
@@ -374,17 +378,22 @@ def main():
         # second block buys is the chip's idle corners -- the tails of the first block's kernels (one workgroup per CU, the slowest CU sets the
         # kernel's time) and its host round trip.  The same K steps run once more one block at a time behind the timed region: the per-kernel
         # times of `roofline` come from THAT region (a kernel's elapsed time beside another block's kernels is not its own).
+        # The payload buffers are the gather pipe's (2 F of them: step k uses buffer k mod 2F); a feeder hands its step over with
+        # submit_step, which keeps the gathers of all ranks in step order whatever order the feeders finish in.
         pyarchon.bind_context(0, local_rank)
         sa_f = [sa_t] + [None if args.no_sa else torch.empty(n, dtype=torch.int32, device=dev) for _ in range(in_flight - 1)]
-        out_f = [torch.empty(n + 4, dtype=torch.uint8, device=dev) for _ in range(in_flight)]
         stage_f = [[] for _ in range(in_flight)]
-        feeders = Feeders(in_flight, local_rank)
-
-        def one_step(t, _k):
-            pyarchon.forward_dev(x_t, sa_f[t], out_f[t][:n], out_f[t][n:].view(torch.int32))
-            stage_f[t].append(pyarchon.stats_raw(local_rank))
+        feeders = Feeders(in_flight, local_rank, on_error=pipe.abort)
 
         def run_steps(count):
+            base = pipe.step_no
+
+            def one_step(t, k):
+                out_t = pipe.buffer_of(base + k)
+                pyarchon.forward_dev(x_t, sa_f[t], out_t[:n], out_t[n:].view(torch.int32))
+                stage_f[t].append(pyarchon.stats_raw(local_rank))
+                pipe.submit_step(base + k)
+
             feeders.run(count, one_step)
 
         # (each thread warms its own context: its arena grows in its first step)
@@ -398,14 +407,16 @@ def main():
         dt = time.perf_counter() - t0
         stage_flight = [s.asdict() for lst in stage_f for s in lst]
         feeders.close()
-        # every thread's last block against the reference's digests (below: thread 0's through the ordinary gate)
+        # every feeder's last block against the reference's digests (the one-at-a-time region's goes through the ordinary gate below)
         flight_ok = True
         ref_f = reference_digest(args.shape, my_block, n)
+        pipe.drain()
+        for back in range(min(in_flight, args.steps)):
+            if ref_f is not None:
+                flight_ok = flight_ok and sha256_of(pipe.outs[(pipe.step_no - 1 - back) % pipe.nbuf].cpu().numpy()) == ref_f["sha256_bwt_base"]
         for t in range(1, in_flight):
-            if ref_f is not None and stage_f[t]:
-                flight_ok = flight_ok and sha256_of(out_f[t].cpu().numpy()) == ref_f["sha256_bwt_base"]
-                if sa_f[t] is not None:
-                    flight_ok = flight_ok and sha256_of(sa_f[t].cpu().numpy()) == ref_f["sha256_P"]
+            if ref_f is not None and sa_f[t] is not None and stage_f[t]:
+                flight_ok = flight_ok and sha256_of(sa_f[t].cpu().numpy()) == ref_f["sha256_P"]
         # ... and the same K steps one block at a time (the calling thread: context 0 again), for the kernels' own times
         for _ in range(2):
             step()
@@ -443,9 +454,6 @@ def main():
     sha_ok = None
     ref = reference_digest(args.shape, my_block, n)
     own_last, gathered_last = pipe.last()
-    if in_flight > 1:
-        sha_first = sha256_of(out_f[0].cpu().numpy()) == ref["sha256_bwt_base"] if ref is not None else True
-        ok = ok and sha_first
     if ref is not None:
         sha_ok = sha256_of(own_last.cpu().numpy()) == ref["sha256_bwt_base"]
         if sa_t is not None:
@@ -527,7 +535,7 @@ def main():
                             % args.block_mib if args.shape == "random" else "%d MiB '%s' block per GPU" % (args.block_mib, args.shape),
                 "block_bytes": n,
                 "blocks_per_step": world,
-                "parallelism": "block-sharded x%d, one RCCL gather of BWT||baseId per step (async, overlapped with the next step)" % world if world > 1 else "single GPU",
+                "parallelism": "block-sharded x%d, one RCCL gather of BWT||baseId per step (async, overlapped with the next steps)" % world if world > 1 else "single GPU",
                 "sa_emitted": sa_t is not None,
                 "sa_lf_consistent": lf_ok,
                 "sa_sha256_matches_reference": sha_ok,     # null: no reference digest committed for this shape / size

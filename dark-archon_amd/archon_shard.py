@@ -50,33 +50,39 @@ class GatherPipe:
     The collective is ISSUED from a helper thread: `submit()` only hands the step over, so the host time of the call into
     torch.distributed (0.1-0.3 ms of Python and C++ per gather) runs beside the next block's kernels instead of in
     front of them -- the forward call that follows releases the GIL for its whole duration.  One helper thread per
-    pipe issues the gathers strictly in step order, on every rank alike."""
+    pipe issues the gathers strictly in step order, on every rank alike.
 
-    def __init__(self, dist, rank, world, payload_bytes, device, via_host=False, dst=0, rotate=False, threaded=True):
+    Several blocks in flight per rank (bench.py --in-flight F): F feeder threads take the steps in turn, `nbuf` = 2 F payload
+    buffers (step k uses buffer k mod nbuf), each feeder asks for the buffer of ITS step (`buffer_of`) and hands the step over with
+    `submit_step`, which waits until every earlier step has been handed over -- the collectives still leave every rank in step order."""
+
+    def __init__(self, dist, rank, world, payload_bytes, device, via_host=False, dst=0, rotate=False, threaded=True, nbuf=2):
         """rotate: the gather of step k lands on rank (dst + k) mod world instead of always on `dst` -- every rank takes its
         turn as the root, so no GPU has to take in world - 1 payloads per step (7 x 256 MiB next to its own sort): the
         outputs of step k (blocks k * world .. k * world + world - 1, one contiguous stretch of the container) then sit
         on rank k mod world, which writes that stretch."""
         self.dist, self.rank, self.world, self.dst, self.via_host, self.rotate = dist, rank, world, dst, via_host, rotate
-        self.outs = [torch.empty(payload_bytes, dtype=torch.uint8, device=device) for _ in range(2)]
+        import threading
+        self.nbuf = nbuf
+        self.outs = [torch.empty(payload_bytes, dtype=torch.uint8, device=device) for _ in range(nbuf)]
         gdev = torch.device("cpu") if via_host else device
-        self.lists = [None, None]
+        self.lists = [None] * nbuf
+        self.cv = threading.Condition()
         if dist is not None and (rotate or rank == dst):
             # A root's own payload is where it belongs already: its slot of the gathered list IS its payload buffer (torch's
             # gather copies the root's input into that slot with copy_, which does nothing when both are one tensor), so a
             # gather moves the world - 1 foreign payloads and nothing else -- 2 x 268 MB of HBM traffic less on the root per
             # step it is root, all of a one-rank gather.
             self.lists = [[self.outs[k] if (r == rank and not via_host) else torch.empty(payload_bytes, dtype=torch.uint8, device=gdev)
-                           for r in range(world)] for k in range(2)]
-        self.pending = [None, None]          # per buffer: the work handle, once the helper has issued the gather
-        self.issued = [None, None]           # per buffer: threading.Event set when the helper has issued it (or failed)
+                           for r in range(world)] for k in range(nbuf)]
+        self.pending = [None] * nbuf         # per buffer: the work handle, once the helper has issued the gather
+        self.issued = [None] * nbuf          # per buffer: threading.Event set when the helper has issued it (or failed)
         self.error = None
         self.step_no = 0
         self.device = device
         self.queue = None
         if dist is not None and threaded:
             import queue
-            import threading
             self.queue = queue.Queue()
             self.thread = threading.Thread(target=self._issuer, daemon=True)
             self.thread.start()
@@ -121,15 +127,39 @@ class GatherPipe:
 
     def next_buffer(self):
         """payload buffer of the coming step (waits until its previous gather has completed)"""
-        k = self.step_no & 1
+        k = self.step_no % self.nbuf
         self._wait(k)
         return self.outs[k]
+
+    def buffer_of(self, step):
+        """payload buffer of step `step` (several feeders: each asks for its own steps, in increasing order; waits until the gather
+        that last used the buffer -- step - nbuf -- has completed)"""
+        k = step % self.nbuf
+        self._wait(k)
+        return self.outs[k]
+
+    def submit_step(self, step):
+        """submit() for several feeders: blocks until every earlier step has been handed over, so that the gathers are issued in step
+        order whatever order the feeders finish in; raises the pipe's error if another feeder (or the helper) has failed meanwhile"""
+        with self.cv:
+            self.cv.wait_for(lambda: self.step_no == step or self.error is not None)
+            if self.error is not None:
+                raise self.error
+            self.submit()
+            self.cv.notify_all()
+
+    def abort(self, err):
+        """a feeder failed outside the pipe: wake the others (their next submit_step raises) -- nothing further is issued"""
+        with self.cv:
+            if self.error is None:
+                self.error = err
+            self.cv.notify_all()
 
     def submit(self):
         """the payload of the current step is complete in its buffer (the producer has synchronised): gather it"""
         if self.error is not None:
             raise self.error
-        k = self.step_no & 1
+        k = self.step_no % self.nbuf
         step = self.step_no
         self.step_no += 1
         if self.dist is None:
@@ -143,7 +173,7 @@ class GatherPipe:
         self.queue.put((k, step, ev))
 
     def drain(self):
-        for k in range(2):
+        for k in range(self.nbuf):
             self._wait(k)
 
     def close(self):
@@ -160,7 +190,7 @@ class GatherPipe:
 
     def last(self):
         """(own payload buffer, gathered list -- valid on last_root() only) of the most recent step"""
-        k = (self.step_no - 1) & 1
+        k = (self.step_no - 1) % self.nbuf
         return self.outs[k], self.lists[k]
 
     def last_root(self):

@@ -145,7 +145,8 @@ def test_bench_two_rank_rehearsal():
                        capture_output=True, text=True, timeout=280, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["blocks_per_step"] == 2
+    assert line["n_gpus"] == 2 and line["config"]["blocks_per_step"] == 2 and line["config"]["blocks_in_flight"] == 2
+    assert line["one_block_at_a_time"]["ms_per_step"] > 0
     assert line["config"]["sa_lf_consistent"] is True and line["config"]["gathered_block_round_trip"] is True
     assert line["value"] > 0 and "roofline" in line and "cpu_baseline" not in line
 

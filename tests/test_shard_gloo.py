@@ -163,3 +163,86 @@ def test_gather_pipe_fails_fast():
     with pytest.raises(Boom):
         pipe.close()
     assert pipe.queue is None           # the helper was stopped all the same
+
+
+def _feeders_worker(rank, world, port, q):
+    """bench.py --in-flight 2 at world 2: two feeder threads per rank take the steps in turn; the SECOND feeder is always done first, and the
+    gathers must still be issued in step order on both ranks (a rank that swapped two would pair step k of one rank with step k+1 of the
+    other, or hang)"""
+    import threading
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "dark-archon_amd"))
+    import archon_shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nbytes, steps, flight = 1000, 12, 2
+    pipe = archon_shard.GatherPipe(dist, rank, world, nbytes, torch.device("cpu"), via_host=False, rotate=True, nbuf=2 * flight)
+    seen = {}
+    lock = threading.Lock()
+
+    def feeder(t):
+        for k in range(t, steps, flight):
+            buf = pipe.buffer_of(k)
+            # the gather that used this buffer last (step k - 4) is complete: its result may be read before the buffer is overwritten
+            if k >= pipe.nbuf and rank == pipe.root_of(k - pipe.nbuf):
+                with lock:
+                    seen[k - pipe.nbuf] = [int(pipe.lists[k % pipe.nbuf][r][0]) for r in range(world)]
+            time.sleep(0.03 if t == 0 else 0.0)          # feeder 1 always arrives first
+            buf[:] = (17 * k + 3 * rank) % 251
+            pipe.submit_step(k)
+
+    ts = [threading.Thread(target=feeder, args=(t,)) for t in range(flight)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    ok = not any(t.is_alive() for t in ts) and pipe.step_no == steps
+    pipe.drain()
+    for k in range(steps - pipe.nbuf, steps):
+        if rank == pipe.root_of(k):
+            seen[k] = [int(pipe.lists[k % pipe.nbuf][r][0]) for r in range(world)]
+    for k, got in seen.items():
+        ok = ok and got == [(17 * k + 3 * r) % 251 for r in range(world)]
+    ok = ok and len(seen) == steps // world
+    pipe.close()
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_pipe_two_feeders_keep_step_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 32500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_feeders_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(2))
+    assert res == {0: True, 1: True}
+
+
+def test_gather_pipe_abort_wakes_the_other_feeder():
+    """a feeder that fails outside the pipe (its transform raised) must not leave the feeder of the NEXT step waiting for it"""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "dark-archon_amd"))
+    import archon_shard
+    pipe = archon_shard.GatherPipe(None, 0, 1, 16, torch.device("cpu"), nbuf=4)
+    out = []
+
+    def second():
+        try:
+            pipe.submit_step(1)          # step 0 is never handed over
+        except RuntimeError as e:
+            out.append(str(e))
+
+    t = threading.Thread(target=second)
+    t.start()
+    pipe.abort(RuntimeError("transform failed"))
+    t.join(10)
+    assert not t.is_alive() and out == ["transform failed"]
+    with pytest.raises(RuntimeError):
+        pipe.submit()
