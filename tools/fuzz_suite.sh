@@ -11,3 +11,5 @@ echo "big blocks ok: $(grep -c 'ok True' $out/big_all.txt)" | tee -a $out/big.tx
 timeout -k 10 200 python3 tools/fuzz_defects.py $((s0+2000)) 100 2>&1 | tail -2 | tee $out/defects.txt
 timeout -k 10 200 python3 tools/stress_objects.py 60 2>&1 | tail -2 | tee $out/stress_objects.txt
 ARCHON_SMALL_BLOCK=0 STRESS_SYNC_ROUTES=1 timeout -k 10 200 python3 tools/stress_objects.py 60 2>&1 | tail -2 | tee -a $out/stress_objects.txt
+timeout -k 10 300 python3 tools/stress_in_flight.py 400 2 256 2>&1 | tail -2 | tee $out/stress_in_flight.txt
+timeout -k 10 300 python3 tools/stress_in_flight.py 300 3 128 2>&1 | tail -2 | tee -a $out/stress_in_flight.txt
