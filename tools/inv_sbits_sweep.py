@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dark-archon_amd"))
 import numpy as np, torch
 import archon_synth as S, pyarchon
-for mib, sweep in ((1, (3, 4, 5, 6)), (4, (3, 4, 5, 6, 7)), (16, (4, 5, 6, 7, 8)), (64, (6, 7, 8, 9))):
+for mib, sweep in ((1, (3, 4, 5, 6)), (4, (3, 4, 5, 6, 7)), (16, (4, 5, 6, 7, 8)), (64, (6, 7, 8, 9)), (128, (7, 8, 9)), (256, (7, 8, 9))):
     n = mib << 20
     x = torch.from_numpy(S.gen_random(n)).cuda()
     bwt = torch.empty_like(x); base = torch.zeros(1, dtype=torch.int32, device="cuda"); out = torch.empty_like(x)
