@@ -1003,8 +1003,17 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
 #undef ARCHON_PASS_B
         iB1 = ps.mark();
         e2 = tm.mark();
-        hipLaunchKernelGGL(bs::k_local_sort, dim3(65536), dim3(bs::kLsBlock), 0, s, B_R, B.prep->start16, n, sa,
-                           d_bwt, d_ctl, B.tie_list, d_skip, defer_big ? 1u : 0u);
+        // (a block of few rows per bucket: the short instance of the bucket sort in front of the general one -- whichever matches the
+        //  count's largest bucket runs, the other returns at once)
+        const uint32_t avg_rows = n >> 16;
+        const uint32_t short_rounds = defer_big ? 0u : avg_rows <= 400u ? 1u : avg_rows <= 1350u ? 3u : 0u;
+        if (short_rounds == 1u)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_local_sort<1>), dim3(65536), dim3(bs::kLsBlock), 0, s, B_R, B.prep->start16, n, sa, d_bwt, d_ctl, B.tie_list, d_skip, 0u, 0u);
+        else if (short_rounds == 3u)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_local_sort<3>), dim3(65536), dim3(bs::kLsBlock), 0, s, B_R, B.prep->start16, n, sa, d_bwt, d_ctl, B.tie_list, d_skip, 0u, 0u);
+        if (short_rounds) ++c->launches;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(bs::k_local_sort<bs::kLsIPT>), dim3(65536), dim3(bs::kLsBlock), 0, s, B_R, B.prep->start16, n, sa,
+                           d_bwt, d_ctl, B.tie_list, d_skip, defer_big ? 1u : 0u, short_rounds * (uint32_t)bs::kLsBlock);
         if (defer_big) {
             hipLaunchKernelGGL(bs::k_unpack_big, dim3(div_up(n, bs::kUnpackChunk)), dim3(256), 0, s, B_R, B.prep->start16, n, sa, d_bwt, d_ctl, d_skip);
             ++c->launches;
