@@ -727,6 +727,34 @@ def test_mid_sizes_lf_consistent(archon, shape, n):
 
 
 @pytest.mark.streaming_machinery
+@pytest.mark.parametrize("n,heavy", [(1 << 20, 0), (1 << 20, 700), (1 << 20, 3000), (24 << 20, 0), (24 << 20, 600), (70 << 20, 0), (70 << 20, 1700),
+                                     (70 << 20, 6000)])
+def test_bucket_sort_instances(archon, oracle, n, heavy):
+    """the bucket sort's short instances (k_local_sort<1>, <3>: blocks whose largest two-byte bucket holds at most 512 / 1536 rows) and
+    the general one behind them: uniform blocks of 16, 384 and 1120 rows per bucket, and the same blocks with ONE bucket pushed over the
+    short instance's limit (the count's largest bucket sends the block to the general instance) or over the sort's capacity"""
+    import torch
+    rng = np.random.default_rng(n + heavy)
+    x = rng.integers(0, 256, size=n, dtype=np.uint8)
+    if heavy:
+        at = rng.choice(n // 8 - 1, size=heavy, replace=False) * 8 + 3
+        x[at] = 0x41
+        x[at + 1] = 0x42                      # `heavy` more rows in the bucket of "AB"
+    if n <= (1 << 20):
+        P, B, b0 = oracle.forward(x)
+        sa, bwt, base = archon.forward(x)
+        assert (sa == P).all() and (bwt == B).all() and base == b0
+    else:
+        x_t = torch.from_numpy(x).cuda()
+        sa_t = torch.empty(n, dtype=torch.int32, device="cuda")
+        bwt_t = torch.empty(n, dtype=torch.uint8, device="cuda")
+        base_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+        archon.forward_dev(x_t, sa_t, bwt_t, base_t)
+        assert archon.validate_dev(x_t, sa_t)
+    assert archon.stats()["path"] == 1
+
+
+@pytest.mark.streaming_machinery
 @pytest.mark.parametrize("ranges", ["1024", "512", "300", "7"])
 def test_many_pass_ranges(archon, oracle, monkeypatch, ranges):
     """bench.py cuts the passes into 1024 ranges for N > 1 (shorter tails when RCCL holds CUs): prefix-summed range
