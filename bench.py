@@ -10,8 +10,12 @@ BWT emitted) on its own 256 MiB block of uniform random bytes already resident
 in HBM (BASELINE.json configs[1], SURVEY.md 8(d) cfg 2;
 block b is seeded SEED_BASE+2+b), and for N>1 the per-block outputs BWT||baseId
 are gathered to rank 0 over RCCL (the path's one exchange step).
-The gather of step k is asynchronous (RCCL's own stream) and overlaps the sort of step k+1; the
-timed region ends only after every gather has completed.  Blocks are independent, per-GPU work is
+The root rotates with the step (step k lands whole on rank k mod N), and the N gathers of N consecutive steps
+-- one per root -- travel as ONE collective (all_to_all_single; --gather-batch 1 = one gather per step): xGMI is
+point to point, a gather uses one link per rank (268 MB at 60-77 GB/s per direction: 3.5-4.5 ms, longer than the sort of
+the step), N rotated gathers at once use every link of every rank.  The exchange of a batch is asynchronous (RCCL's own
+stream) and overlaps the sorts of the next batch; the
+timed region ends only after every exchange has completed.  Blocks are independent, per-GPU work is
 fixed: "scaling": "weak".  Every rank keeps TWO blocks in flight (--in-flight,
 config.blocks_in_flight): two feeder threads, each bound to its own compute context of the library
 (include/archon_hip.h: "two threads feeding one GPU"), take the K steps in turn -- every step is
@@ -289,6 +293,9 @@ def main():
                     "0 = default: 2 (per rank, whatever N: the gathers of N > 1 are still issued in step order)")
     ap.add_argument("--gather-root", default="rotate", help="rotate (step k gathers on rank k mod N: no GPU takes in N-1 payloads "
                     "every step) | 0 (always rank 0)")
+    ap.add_argument("--gather-batch", type=int, default=0, help="0 = default: at N > 1 with rotating roots the N gathers of N consecutive steps (one per "
+                    "root) travel as ONE collective (all_to_all_single: every xGMI link of every rank carries one payload at once) | 1: one "
+                    "gather per step (one link per rank and step; A/B runs)")
     ap.add_argument("--gather-threaded", type=int, default=1, help="1: the gather is issued from the pipe's helper thread (default) | 0: from "
                     "the calling thread (A/B runs)")
     ap.add_argument("--pass-ranges", type=int, default=-1, help="library option pass_ranges (default: one per CU at N=1, 1024 at N>1)")
@@ -332,8 +339,9 @@ def main():
     # BWT || baseId (LE), double-buffered: the gather of step k runs on RCCL's stream while step k+1 sorts
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
     in_flight = max(1, min(args.in_flight if args.in_flight > 0 else 2, 4, args.steps))
+    gather_batch = world if (world > 1 and args.gather_root == "rotate" and args.gather_batch != 1) else 1
     pipe = archon_shard.GatherPipe(dist, rank, world, n + 4, dev, via_host=(args.backend != "nccl"), rotate=(args.gather_root == "rotate"),
-                                   threaded=bool(args.gather_threaded), nbuf=2 * in_flight)
+                                   threaded=bool(args.gather_threaded), nbuf=2 * in_flight, batch=gather_batch)
     pass_ranges = 0
     if world > 1:
         # RCCL's send/recv kernels hold CUs while the gather of step k overlaps the sort of step k+1, and a pass
@@ -546,7 +554,9 @@ def main():
                 "backend": (dist.get_backend() if dist is not None else None),
                 "dist_world_size": (dist.get_world_size() if dist is not None else 1),
                 "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if dist is not None and args.backend == "nccl" else None),
-                "exchange": ("torch.distributed.gather (RCCL grouped send/recv) of %d bytes per rank per step, root %s" % (n + 4, "k mod N at step k" if args.gather_root == "rotate" else "0")) if dist is not None else None,
+                "exchange": (("torch.distributed.all_to_all_single (RCCL grouped send/recv): the %d gathers of %d consecutive steps, root k mod N at step k, as one "
+                              "collective; %d bytes per rank and step" % (world, world, n + 4)) if pipe.batch > 1 else
+                             ("torch.distributed.gather (RCCL grouped send/recv) of %d bytes per rank per step, root %s" % (n + 4, "k mod N at step k" if args.gather_root == "rotate" else "0"))) if dist is not None else None,
             },
             "roofline": {
                 "bound": "hbm",

@@ -54,21 +54,47 @@ class GatherPipe:
 
     Several blocks in flight per rank (bench.py --in-flight F): F feeder threads take the steps in turn, `nbuf` = 2 F payload
     buffers (step k uses buffer k mod nbuf), each feeder asks for the buffer of ITS step (`buffer_of`) and hands the step over with
-    `submit_step`, which waits until every earlier step has been handed over -- the collectives still leave every rank in step order."""
+    `submit_step`, which waits until every earlier step has been handed over -- the collectives still leave every rank in step order.
 
-    def __init__(self, dist, rank, world, payload_bytes, device, via_host=False, dst=0, rotate=False, threaded=True, nbuf=2):
+    `batch` = world (rotating roots only): the gathers of `world` consecutive steps -- one per root -- are issued as ONE collective
+    (`all_to_all_single`: chunk j of a rank's send buffer is its payload of the step whose root is rank j; chunk r of the
+    receive buffer on rank j is rank r's payload of that step).  xGMI is point to point: a gather moves a rank's N + 4 bytes
+    over the ONE link to that step's root (268 MB at 60-77 GB/s per direction = 3.5-4.5 ms, longer than the 2.6 ms sort of the
+    step) while its other six links idle; `world` rotated gathers in one collective use every link of every rank at once, so the
+    same 3.5-4.5 ms carry `world` steps.  Blocks land exactly where the per-step gathers put them (step k whole on rank k mod
+    world).  Two batches of buffers: batch b is exchanged while batch b + 1 is sorted.  `drain()` exchanges a batch that is not
+    full yet as it stands (every rank drains at the same step); its steps travel again when the batch completes."""
+
+    def __init__(self, dist, rank, world, payload_bytes, device, via_host=False, dst=0, rotate=False, threaded=True, nbuf=2, batch=1):
         """rotate: the gather of step k lands on rank (dst + k) mod world instead of always on `dst` -- every rank takes its
         turn as the root, so no GPU has to take in world - 1 payloads per step (7 x 256 MiB next to its own sort): the
         outputs of step k (blocks k * world .. k * world + world - 1, one contiguous stretch of the container) then sit
         on rank k mod world, which writes that stretch."""
         self.dist, self.rank, self.world, self.dst, self.via_host, self.rotate = dist, rank, world, dst, via_host, rotate
         import threading
-        self.nbuf = nbuf
-        self.outs = [torch.empty(payload_bytes, dtype=torch.uint8, device=device) for _ in range(nbuf)]
+        self.batch = int(batch) if (dist is not None and world > 1 and int(batch) > 1) else 1
         gdev = torch.device("cpu") if via_host else device
-        self.lists = [None] * nbuf
         self.cv = threading.Condition()
-        if dist is not None and (rotate or rank == dst):
+        self.covered = 0                     # batch mode: steps 0 .. covered-1 are inside an exchange that has been handed to the helper
+        if self.batch > 1:
+            if self.batch != world or not rotate or dst != 0:
+                raise ValueError("GatherPipe: batch must equal the world size, with rotating roots from rank 0")
+            nbuf = 2 * world
+            # a slot = one payload, on a 256-byte boundary (the kernels store the BWT 16 bytes at a time)
+            self.stride = stride = (payload_bytes + 255) & ~255
+            self.send = [torch.empty(world * stride, dtype=torch.uint8, device=device) for _ in range(2)]
+            self.recv = [torch.empty(world * stride, dtype=torch.uint8, device=gdev) for _ in range(2)]
+        self.nbuf = nbuf
+        if self.batch > 1:
+            # step k: buffer k mod 2W = slot k mod W of batch buffer (k div W) mod 2; its root (rank k mod W) finds the payloads of all ranks
+            # in the receive buffer of the same parity
+            self.outs = [self.send[k // world][(k % world) * stride:(k % world) * stride + payload_bytes] for k in range(nbuf)]
+            self.lists = [[self.recv[k // world][r * stride:r * stride + payload_bytes] for r in range(world)] if k % world == rank else None
+                          for k in range(nbuf)]
+        else:
+            self.outs = [torch.empty(payload_bytes, dtype=torch.uint8, device=device) for _ in range(nbuf)]
+            self.lists = [None] * nbuf
+        if self.batch == 1 and dist is not None and (rotate or rank == dst):
             # A root's own payload is where it belongs already: its slot of the gathered list IS its payload buffer (torch's
             # gather copies the root's input into that slot with copy_, which does nothing when both are one tensor), so a
             # gather moves the world - 1 foreign payloads and nothing else -- 2 x 268 MB of HBM traffic less on the root per
@@ -95,6 +121,11 @@ class GatherPipe:
         root = self.root_of(step)
         self.pending[k] = self.dist.gather(src, self.lists[k] if self.rank == root else None, dst=root, async_op=True)
 
+    def _exchange(self, g):
+        """batch mode: the `world` rotated gathers of one batch as one collective (equal splits: one slot per peer)"""
+        src = self.send[g].cpu() if self.via_host else self.send[g]
+        self.pending[g] = self.dist.all_to_all_single(self.recv[g], src, async_op=True)
+
     def _issuer(self):
         if self.device is not None and getattr(self.device, "type", "cpu") == "cuda":
             torch.cuda.set_device(self.device)
@@ -105,13 +136,37 @@ class GatherPipe:
             k, step, ev = job
             if self.error is None:
                 try:
-                    self._issue(k, step)
+                    if step is None:
+                        self._exchange(k)
+                    else:
+                        self._issue(k, step)
                 except Exception as e:      # noqa: BLE001
                     # The first failure ends the pipe: no later gather is issued (a rank that went on issuing collectives its
                     # peers never match would block them until the NCCL timeout), every job still queued has its event set,
                     # and the owner thread learns at its very next call (submit / next_buffer / drain all raise self.error).
                     self.error = e
             ev.set()
+
+    def _wait_batch(self, need):
+        """batch mode: step `need` (the last user of a buffer; < 0: none) has been exchanged -- first handed over (by whichever
+        feeder completed its batch, or by a drain), then issued by the helper, then complete.  Several feeders may wait for one
+        batch: nothing is reset here, and over RCCL each caller's own stream waits for the collective."""
+        if need >= 0:
+            with self.cv:
+                self.cv.wait_for(lambda: self.covered > need or self.error is not None)
+        if self.error is not None:
+            raise self.error
+        if need < 0:
+            return
+        g = (need // self.batch) % 2
+        ev = self.issued[g]
+        if ev is not None:
+            ev.wait()
+        if self.error is not None:
+            raise self.error
+        work = self.pending[g]
+        if work is not None and not work.is_completed():
+            work.wait()
 
     def _wait(self, k):
         if self.issued[k] is not None:
@@ -128,14 +183,20 @@ class GatherPipe:
     def next_buffer(self):
         """payload buffer of the coming step (waits until its previous gather has completed)"""
         k = self.step_no % self.nbuf
-        self._wait(k)
+        if self.batch > 1:
+            self._wait_batch(self.step_no - self.nbuf)
+        else:
+            self._wait(k)
         return self.outs[k]
 
     def buffer_of(self, step):
         """payload buffer of step `step` (several feeders: each asks for its own steps, in increasing order; waits until the gather
         that last used the buffer -- step - nbuf -- has completed)"""
         k = step % self.nbuf
-        self._wait(k)
+        if self.batch > 1:
+            self._wait_batch(step - self.nbuf)
+        else:
+            self._wait(k)
         return self.outs[k]
 
     def submit_step(self, step):
@@ -159,6 +220,12 @@ class GatherPipe:
         """the payload of the current step is complete in its buffer (the producer has synchronised): gather it"""
         if self.error is not None:
             raise self.error
+        if self.batch > 1:
+            with self.cv:
+                self.step_no += 1
+                if self.step_no % self.batch == 0:
+                    self._hand_over_batch()
+            return
         k = self.step_no % self.nbuf
         step = self.step_no
         self.step_no += 1
@@ -172,7 +239,34 @@ class GatherPipe:
         self.issued[k] = ev
         self.queue.put((k, step, ev))
 
+    def _hand_over_batch(self):
+        """(under self.cv) the batch that holds step step_no - 1 goes to the helper -- or is issued here -- as it stands"""
+        g = ((self.step_no - 1) // self.batch) % 2
+        if self.queue is None:
+            try:
+                self._exchange(g)
+            except Exception as e:      # noqa: BLE001
+                self.error = e
+                self.cv.notify_all()
+                raise
+        else:
+            import threading
+            ev = threading.Event()
+            self.issued[g] = ev
+            self.queue.put((g, None, ev))
+        self.covered = self.step_no
+        self.cv.notify_all()
+
     def drain(self):
+        if self.batch > 1:
+            with self.cv:
+                if self.error is None and self.covered < self.step_no:
+                    self._hand_over_batch()
+            self._wait_batch(self.step_no - 1 - self.batch)       # the batch before the last one (if any) ...
+            self._wait_batch(self.step_no - 1)                    # ... and the last one
+            if self.error is not None:
+                raise self.error
+            return
         for k in range(self.nbuf):
             self._wait(k)
 

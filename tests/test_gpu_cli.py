@@ -131,22 +131,26 @@ def test_container_rejects_plain_file(archon, tmp_path):
     assert r.returncode != 0
 
 
-def test_bench_two_rank_rehearsal():
-    """bench.py's N>1 control flow (double-buffered async gather, barriers, max-over-ranks clock, decode of the
-    block gathered from the last rank) with 2 ranks sharing this one GPU over gloo.  Not a measurement."""
+@pytest.mark.parametrize("ranks,steps,extra", [(2, 2, []), (2, 5, ["--gather-batch", "1"]), (3, 7, []), (2, 5, ["--in-flight", "1"])])
+def test_bench_two_rank_rehearsal(ranks, steps, extra):
+    """bench.py's N>1 control flow (the rotated gathers of N steps as one exchange -- full batches and the part of one a fence finds --,
+    or one gather per step; barriers, max-over-ranks clock, decode of the block gathered from the last rank) with 2 or 3 ranks
+    sharing this one GPU over gloo.  Not a measurement."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                         "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--block-mib", "8", "--backend", "gloo"],
+                        "--gpus", str(ranks), "--steps", str(steps), "--warmup", "1", "--block-mib", "8", "--backend", "gloo"] + extra,
                        capture_output=True, text=True, timeout=280, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["blocks_per_step"] == 2 and line["config"]["blocks_in_flight"] == 2
-    assert line["one_block_at_a_time"]["ms_per_step"] > 0
+    flight = 1 if "--in-flight" in extra else 2
+    assert line["n_gpus"] == ranks and line["config"]["blocks_per_step"] == ranks and line["config"]["blocks_in_flight"] == flight
+    assert ("one_block_at_a_time" in line) == (flight > 1)
+    assert ("all_to_all_single" in line["config"]["exchange"]) == ("--gather-batch" not in extra)
     assert line["config"]["sa_lf_consistent"] is True and line["config"]["gathered_block_round_trip"] is True
     assert line["value"] > 0 and "roofline" in line and "cpu_baseline" not in line
 

@@ -70,22 +70,26 @@ def test_block_assignment():
     assert bwt.tolist() == [1, 2, 3] and base == 0x01020304
 
 
-def _pipe_worker(rank, world, port, rotate, q, via_host=True, threaded=True):
+def _pipe_worker(rank, world, port, rotate, q, via_host=True, threaded=True, batch=1, drain_every=1):
     sys.path.insert(0, os.path.join(ROOT, "dark-archon_amd"))
     import archon_shard
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    nbytes, steps = 1000, 5
-    pipe = archon_shard.GatherPipe(dist, rank, world, nbytes, torch.device("cpu"), via_host=via_host, rotate=rotate, threaded=threaded)
+    nbytes, steps = 1000, 5 if batch == 1 else 11
+    pipe = archon_shard.GatherPipe(dist, rank, world, nbytes, torch.device("cpu"), via_host=via_host, rotate=rotate, threaded=threaded, batch=batch)
     ok = True
-    if not via_host and (rotate or rank == 0):
+    if batch > 1:
+        ok = pipe.batch == world and pipe.nbuf == 2 * world and all((o.data_ptr() - pipe.send[0].data_ptr()) % 256 == 0 for o in pipe.outs[:world])
+    elif not via_host and (rotate or rank == 0):
         # the branch the RCCL run takes: a root's own slot of the gathered list IS its payload buffer
         ok = all(pipe.lists[k][rank] is pipe.outs[k] for k in range(2))
     for k in range(steps):
         buf = pipe.next_buffer()
         buf[:] = (17 * k + 3 * rank) % 251               # the payload of (step k, rank)
         pipe.submit()
+        if (k + 1) % drain_every and k != steps - 1:
+            continue                                      # (batch mode: also without a drain between the steps of a batch)
         pipe.drain()                                      # (the bench overlaps; here every step is checked at once)
         root = pipe.root_of(k)
         ok = ok and root == ((k % world) if rotate else 0) and pipe.last_root() == root
@@ -134,6 +138,43 @@ def test_gather_pipe_aliased_root_slot(rotate, threaded):
     assert res == {0: True, 1: True}
 
 
+@pytest.mark.parametrize("drain_every", [1, 3, 100])
+@pytest.mark.parametrize("threaded", [True, False])
+@pytest.mark.parametrize("via_host", [True, False])
+def test_gather_pipe_batched_exchange(via_host, threaded, drain_every):
+    """bench.py's exchange at N > 1: the `world` rotated gathers of a batch as ONE all_to_all_single (every xGMI link of every rank
+    carries one payload at once, instead of one link per rank and step).  Every step's payloads are compared on the step's root
+    (rank k mod world) -- with a drain behind every step (a batch that is not full travels as it stands, and again when it completes),
+    behind every third, and only at the end (11 steps at world 2: five full batches and a half)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 1000) + (7 if via_host else 0) + (13 if threaded else 0) + drain_every % 29
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, True, q, via_host, threaded, 2, drain_every)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(2))
+    assert res == {0: True, 1: True}
+
+
+def test_gather_pipe_batch_needs_rotating_roots():
+    sys.path.insert(0, os.path.join(ROOT, "dark-archon_amd"))
+    import archon_shard
+
+    class FakeDist:
+        pass
+
+    with pytest.raises(ValueError):
+        archon_shard.GatherPipe(FakeDist(), 0, 2, 16, torch.device("cpu"), via_host=True, rotate=False, batch=2)
+    with pytest.raises(ValueError):
+        archon_shard.GatherPipe(FakeDist(), 0, 4, 16, torch.device("cpu"), via_host=True, rotate=True, batch=2)
+    # one rank, or no process group: the per-step path (a one-rank gather moves nothing: the root's slot IS its payload buffer)
+    assert archon_shard.GatherPipe(None, 0, 1, 16, torch.device("cpu"), batch=1).batch == 1
+    assert archon_shard.GatherPipe(FakeDist(), 0, 1, 16, torch.device("cpu"), rotate=True, batch=1, threaded=False).batch == 1
+
+
 def test_gather_pipe_fails_fast():
     """the first exception of the helper thread ends the pipe -- no later gather is issued, and the owner's next
     call raises instead of leaving its peers in a collective nobody matches"""
@@ -165,7 +206,7 @@ def test_gather_pipe_fails_fast():
     assert pipe.queue is None           # the helper was stopped all the same
 
 
-def _feeders_worker(rank, world, port, q):
+def _feeders_worker(rank, world, port, q, batch=1):
     """bench.py --in-flight 2 at world 2: two feeder threads per rank take the steps in turn; the SECOND feeder is always done first, and the
     gathers must still be issued in step order on both ranks (a rank that swapped two would pair step k of one rank with step k+1 of the
     other, or hang)"""
@@ -177,7 +218,7 @@ def _feeders_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     nbytes, steps, flight = 1000, 12, 2
-    pipe = archon_shard.GatherPipe(dist, rank, world, nbytes, torch.device("cpu"), via_host=False, rotate=True, nbuf=2 * flight)
+    pipe = archon_shard.GatherPipe(dist, rank, world, nbytes, torch.device("cpu"), via_host=False, rotate=True, nbuf=2 * flight, batch=batch)
     seen = {}
     lock = threading.Lock()
 
@@ -211,11 +252,14 @@ def _feeders_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gather_pipe_two_feeders_keep_step_order():
+@pytest.mark.parametrize("batch", [1, 2])
+def test_gather_pipe_two_feeders_keep_step_order(batch):
+    """batch = 2 (= world): the two rotated gathers of a batch travel as one all_to_all_single; a buffer is handed out again only when
+    the exchange of the batch that used it last is complete, whichever feeder completed that batch"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 32500 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_feeders_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 32500 + (os.getpid() % 1000) + 17 * batch
+    procs = [ctx.Process(target=_feeders_worker, args=(r, 2, port, q, batch)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
