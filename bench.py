@@ -295,7 +295,7 @@ def main():
                     "every step) | 0 (always rank 0)")
     ap.add_argument("--gather-batch", type=int, default=0, help="0 = default: at N > 1 with rotating roots the N gathers of N consecutive steps (one per "
                     "root) travel as ONE collective (all_to_all_single: every xGMI link of every rank carries one payload at once) | 1: one "
-                    "gather per step (one link per rank and step; A/B runs)")
+                    "gather per step (one link per rank and step; A/B runs) | -1: the batched exchange even with one rank (the collective's self-test)")
     ap.add_argument("--gather-threaded", type=int, default=1, help="1: the gather is issued from the pipe's helper thread (default) | 0: from "
                     "the calling thread (A/B runs)")
     ap.add_argument("--pass-ranges", type=int, default=-1, help="library option pass_ranges (default: one per CU at N=1, 1024 at N>1)")
@@ -339,7 +339,7 @@ def main():
     # BWT || baseId (LE), double-buffered: the gather of step k runs on RCCL's stream while step k+1 sorts
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
     in_flight = max(1, min(args.in_flight if args.in_flight > 0 else 2, 4, args.steps))
-    gather_batch = world if (world > 1 and args.gather_root == "rotate" and args.gather_batch != 1) else 1
+    gather_batch = -1 if args.gather_batch < 0 else (world if (world > 1 and args.gather_root == "rotate" and args.gather_batch != 1) else 1)
     pipe = archon_shard.GatherPipe(dist, rank, world, n + 4, dev, via_host=(args.backend != "nccl"), rotate=(args.gather_root == "rotate"),
                                    threaded=bool(args.gather_threaded), nbuf=2 * in_flight, batch=gather_batch)
     pass_ranges = 0
@@ -555,7 +555,7 @@ def main():
                 "dist_world_size": (dist.get_world_size() if dist is not None else 1),
                 "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if dist is not None and args.backend == "nccl" else None),
                 "exchange": (("torch.distributed.all_to_all_single (RCCL grouped send/recv): the %d gathers of %d consecutive steps, root k mod N at step k, as one "
-                              "collective; %d bytes per rank and step" % (world, world, n + 4)) if pipe.batch > 1 else
+                              "collective; %d bytes per rank and step" % (world, world, n + 4)) if pipe.batched else
                              ("torch.distributed.gather (RCCL grouped send/recv) of %d bytes per rank per step, root %s" % (n + 4, "k mod N at step k" if args.gather_root == "rotate" else "0"))) if dist is not None else None,
             },
             "roofline": {

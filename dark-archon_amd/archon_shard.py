@@ -72,12 +72,14 @@ class GatherPipe:
         on rank k mod world, which writes that stretch."""
         self.dist, self.rank, self.world, self.dst, self.via_host, self.rotate = dist, rank, world, dst, via_host, rotate
         import threading
-        self.batch = int(batch) if (dist is not None and world > 1 and int(batch) > 1) else 1
+        # batch < 0: the batched exchange whatever the world size (one rank: the collective's self-test under RCCL, a local copy)
+        self.batched = dist is not None and (int(batch) < 0 or (world > 1 and int(batch) > 1))
+        self.batch = world if self.batched else 1
         gdev = torch.device("cpu") if via_host else device
         self.cv = threading.Condition()
         self.covered = 0                     # batch mode: steps 0 .. covered-1 are inside an exchange that has been handed to the helper
-        if self.batch > 1:
-            if self.batch != world or not rotate or dst != 0:
+        if self.batched:
+            if (int(batch) > 0 and int(batch) != world) or not rotate or dst != 0:
                 raise ValueError("GatherPipe: batch must equal the world size, with rotating roots from rank 0")
             nbuf = 2 * world
             # a slot = one payload, on a 256-byte boundary (the kernels store the BWT 16 bytes at a time)
@@ -85,7 +87,7 @@ class GatherPipe:
             self.send = [torch.empty(world * stride, dtype=torch.uint8, device=device) for _ in range(2)]
             self.recv = [torch.empty(world * stride, dtype=torch.uint8, device=gdev) for _ in range(2)]
         self.nbuf = nbuf
-        if self.batch > 1:
+        if self.batched:
             # step k: buffer k mod 2W = slot k mod W of batch buffer (k div W) mod 2; its root (rank k mod W) finds the payloads of all ranks
             # in the receive buffer of the same parity
             self.outs = [self.send[k // world][(k % world) * stride:(k % world) * stride + payload_bytes] for k in range(nbuf)]
@@ -94,7 +96,7 @@ class GatherPipe:
         else:
             self.outs = [torch.empty(payload_bytes, dtype=torch.uint8, device=device) for _ in range(nbuf)]
             self.lists = [None] * nbuf
-        if self.batch == 1 and dist is not None and (rotate or rank == dst):
+        if not self.batched and dist is not None and (rotate or rank == dst):
             # A root's own payload is where it belongs already: its slot of the gathered list IS its payload buffer (torch's
             # gather copies the root's input into that slot with copy_, which does nothing when both are one tensor), so a
             # gather moves the world - 1 foreign payloads and nothing else -- 2 x 268 MB of HBM traffic less on the root per
@@ -183,7 +185,7 @@ class GatherPipe:
     def next_buffer(self):
         """payload buffer of the coming step (waits until its previous gather has completed)"""
         k = self.step_no % self.nbuf
-        if self.batch > 1:
+        if self.batched:
             self._wait_batch(self.step_no - self.nbuf)
         else:
             self._wait(k)
@@ -193,7 +195,7 @@ class GatherPipe:
         """payload buffer of step `step` (several feeders: each asks for its own steps, in increasing order; waits until the gather
         that last used the buffer -- step - nbuf -- has completed)"""
         k = step % self.nbuf
-        if self.batch > 1:
+        if self.batched:
             self._wait_batch(step - self.nbuf)
         else:
             self._wait(k)
@@ -220,7 +222,7 @@ class GatherPipe:
         """the payload of the current step is complete in its buffer (the producer has synchronised): gather it"""
         if self.error is not None:
             raise self.error
-        if self.batch > 1:
+        if self.batched:
             with self.cv:
                 self.step_no += 1
                 if self.step_no % self.batch == 0:
@@ -258,7 +260,7 @@ class GatherPipe:
         self.cv.notify_all()
 
     def drain(self):
-        if self.batch > 1:
+        if self.batched:
             with self.cv:
                 if self.error is None and self.covered < self.step_no:
                     self._hand_over_batch()

@@ -79,7 +79,7 @@ def _pipe_worker(rank, world, port, rotate, q, via_host=True, threaded=True, bat
     nbytes, steps = 1000, 5 if batch == 1 else 11
     pipe = archon_shard.GatherPipe(dist, rank, world, nbytes, torch.device("cpu"), via_host=via_host, rotate=rotate, threaded=threaded, batch=batch)
     ok = True
-    if batch > 1:
+    if batch != 1:
         ok = pipe.batch == world and pipe.nbuf == 2 * world and all((o.data_ptr() - pipe.send[0].data_ptr()) % 256 == 0 for o in pipe.outs[:world])
     elif not via_host and (rotate or rank == 0):
         # the branch the RCCL run takes: a root's own slot of the gathered list IS its payload buffer
@@ -157,6 +157,19 @@ def test_gather_pipe_batched_exchange(via_host, threaded, drain_every):
         assert p.exitcode == 0
     res = dict(q.get(timeout=10) for _ in range(2))
     assert res == {0: True, 1: True}
+
+
+def test_gather_pipe_batched_exchange_one_rank():
+    """bench.py --gather-batch -1 under torch.distributed.run with ONE rank: the batched exchange as the collective's self-test (the
+    only form of it a one-GPU box can run over RCCL)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 34500 + (os.getpid() % 1000)
+    p = ctx.Process(target=_pipe_worker, args=(0, 1, port, True, q, False, True, -1, 3))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0
+    assert q.get(timeout=10) == (0, True)
 
 
 def test_gather_pipe_batch_needs_rotating_roots():
