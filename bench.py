@@ -298,7 +298,8 @@ def main():
                     "gather per step (one link per rank and step; A/B runs) | -1: the batched exchange even with one rank (the collective's self-test)")
     ap.add_argument("--gather-threaded", type=int, default=1, help="1: the gather is issued from the pipe's helper thread (default) | 0: from "
                     "the calling thread (A/B runs)")
-    ap.add_argument("--pass-ranges", type=int, default=-1, help="library option pass_ranges (default: one per CU at N=1, 1024 at N>1)")
+    ap.add_argument("--pass-ranges", type=int, default=-1, help="library option pass_ranges (default: one per CU at N=1, 224 at N>1: 32 CUs left to RCCL's kernels)")
+    ap.add_argument("--pass-b-buckets", type=int, default=-1, help="library option pass_b_buckets (default: the library's own, 1; 0 = pass B by ranges: A/B runs)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the measured configuration) | gloo (rehearsal of the N>1 "
                     "control flow on fewer GPUs than ranks: ranks share devices, the gather is staged through host memory)")
     args = ap.parse_args()
@@ -344,16 +345,21 @@ def main():
                                    threaded=bool(args.gather_threaded), nbuf=2 * in_flight, batch=gather_batch)
     pass_ranges = 0
     if world > 1:
-        # RCCL's send/recv kernels hold CUs while the gather of step k overlaps the sort of step k+1, and a pass
-        # workgroup needs a whole CU (all its registers): with one range per CU a few lost CUs mean a second round,
-        # i.e. a pass twice as long.  1024 ranges keep that tail at a quarter of a round.
-        # Product options of the library (include/archon_hip.h, archon_hip_set_option), per device.
-        pass_ranges = args.pass_ranges if args.pass_ranges >= 0 else 1024
+        # RCCL's send/recv kernels hold CUs while the exchange of a batch overlaps the sorts of the next one, and a pass workgroup
+        # needs a whole CU (all its LDS): with one range per CU a few held CUs mean a second round of workgroups, i.e. a pass twice
+        # as long.  224 ranges leave 32 CUs to RCCL (and to the other block in flight); with two blocks in flight they cost nothing
+        # when no exchange runs (profiles/r05_final/in_flight_sweep.txt: 103.1 GB/s against 102.3 at 256).  Measured with one rank
+        # over RCCL and a 268 MB self-exchange beside every step (profiles/r05_final/exchange/exchange_ranges.txt): 224 ranges with
+        # pass B by buckets 92.9 GB/s, 256 ranges 90.8, 224 ranges with pass B by ranges 85.7, 1024 ranges with pass B by ranges
+        # (what this script asked for before) 82.9 -- and without an exchange 100.0 / 90.4 / 89.0 for 256 by buckets / 224 by
+        # ranges / 1024 by ranges.  Product options of the library (include/archon_hip.h, archon_hip_set_option), per device.
+        pass_ranges = args.pass_ranges if args.pass_ranges >= 0 else 224
         pyarchon.set_option("pass_ranges", pass_ranges, local_rank)
-        pyarchon.set_option("pass_b_buckets", 0, local_rank)
     elif args.pass_ranges > 0:
         pass_ranges = args.pass_ranges
         pyarchon.set_option("pass_ranges", pass_ranges, local_rank)
+    if args.pass_b_buckets >= 0:
+        pyarchon.set_option("pass_b_buckets", args.pass_b_buckets, local_rank)
     # (no archon_hip_reserve: the arenas grow in the warm-up step, by what the block really needs -- a block the streaming stage settles
     #  never allocates the general stage's lists and tables; pipeline.arena_bytes_per_input_byte says what the timed steps used)
 

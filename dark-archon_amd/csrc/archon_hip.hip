@@ -1393,6 +1393,11 @@ static int forward_run(Ctx *c, hipStream_t s, const uint8_t *d_x_in, uint32_t n,
                     }
                     h0 = key_bytes;
                 }
+                if (g_route.key_bytes >= 3 && g_route.key_bytes < (int)fwd::kKeyBytes && key_bytes == fwd::kKeyBytes && period_hint == 0) {
+                    key_bytes = (uint32_t)g_route.key_bytes;       // (tests / experiments: the order never depends on the depth)
+                    shallow = true;
+                    h0 = key_bytes;
+                }
                 if (!tail_fetched) {
                     ARCHON_HIP_TRY(hipMemcpyAsync(c->h_mail + 520, d_x + (n - 8), 8, hipMemcpyDeviceToHost, s));
                     ARCHON_SYNC(s);
@@ -2339,6 +2344,7 @@ int archon_hip_test_route(const char *name, long value)
     if (!strcmp(name, "REL_MIN_SEG")) { g_route.rel_min_seg = value; return ARCHON_OK; }
     if (!strcmp(name, "INV_ROWS")) { g_route.inv_rows = value < 0 ? -1 : value > 2 ? 1 : (int)value; return ARCHON_OK; }
     if (!strcmp(name, "INV_SLAB")) { g_route.inv_slab = value > 0 ? (uint32_t)value : 0u; return ARCHON_OK; }
+    if (!strcmp(name, "KEY_BYTES")) { g_route.key_bytes = (int)value; return ARCHON_OK; }
     if (!strcmp(name, "INV_SBITS")) { g_route.inv_sbits = (int)value; return ARCHON_OK; }
     if (!strcmp(name, "INV_WALK_WGS")) { g_route.inv_walk_wgs = (int)value; return ARCHON_OK; }
     for (const auto &f : kFlags)

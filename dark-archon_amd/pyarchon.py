@@ -136,7 +136,7 @@ _routes_seen = None
 # before the next call into the library.
 _ROUTE_NAMES = ("FORCE_PATH", "SMALL_BLOCK", "PASS_RANGES", "INV_ROWS", "INV_SLAB", "INV_SBITS", "INV_WALK_WGS", "NO_ALIGNED", "NO_CHAINS", "NO_DEEP_HINT",
                 "NO_PACK", "NO_PACK_STREAM", "NO_PAIR_CHAINS", "NO_PERIOD_HINT", "NO_BREAK_ROUND", "NO_PERIOD_PROBE", "NO_PERIOD_STREAM", "NO_PROBE",
-                "NO_RANK_WRITER", "NO_TEXT_ROUNDS", "NO_MID", "NO_SHALLOW", "NO_CLOSED_FORM", "NO_REL_RECORDS", "ALIGNED_MIN", "REL_MIN_SEG")
+                "NO_RANK_WRITER", "NO_TEXT_ROUNDS", "NO_MID", "NO_SHALLOW", "NO_CLOSED_FORM", "NO_REL_RECORDS", "ALIGNED_MIN", "REL_MIN_SEG", "KEY_BYTES")
 
 
 def _sync_routes(L):

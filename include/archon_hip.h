@@ -177,9 +177,10 @@ int archon_hip_bind_context(int dev, int slot);
 int archon_hip_context_of_thread(int dev);
 
 /* Product options, per device; read by every transform on that device when it starts.
- *   "pass_ranges"     ranges the two streaming LSB passes are cut into: 0 = one per CU (default), 1..1024.  More, shorter
- *                     ranges shorten the tail when other kernels hold CUs beside the sort (RCCL's copy kernels while a
- *                     gather overlaps the next block: bench.py asks for 1024 at N > 1).
+ *   "pass_ranges"     ranges the two streaming LSB passes are cut into: 0 = one per CU (default), 1..1024.  A pass workgroup
+ *                     takes a whole CU: fewer ranges than CUs leave CUs to kernels that run beside the sort (RCCL's copy
+ *                     kernels while an exchange overlaps the next blocks: bench.py asks for 224 at N > 1); more, shorter
+ *                     ranges shorten the tail instead, at 9 % of the passes' speed.
  *   "pass_b_buckets"  1 (default): LSB pass B deals whole second-byte buckets, one per workgroup, when the block is
  *                     balanced; 0: always by ranges (every workgroup the same work: again for a chip that is shared).
  * Every setting yields the same output. */

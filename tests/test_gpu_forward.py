@@ -491,6 +491,22 @@ def test_key_depth_follows_the_byte_counts(archon, oracle, no_shallow, monkeypat
     assert (sa == P).all() and (bwt == B).all() and base == b0
 
 
+@pytest.mark.small_block_default
+@pytest.mark.parametrize("key_bytes", ["3", "4", "5", "6"])
+def test_forced_key_depth(archon, oracle, key_bytes, monkeypatch):
+    """route KEY_BYTES (tools/key_bytes_sweep.py): the LSB passes of the 7-pass route sort on that many key bytes, the rounds take
+    the ties at that depth; the order never depends on it (on real text every byte less costs 2.4 - 3.6 ms of rounds and saves
+    1.35 ms of passes at 256 MiB: profiles/r05_final/key_bytes_sweep.txt -- seven stays)"""
+    monkeypatch.setenv("ARCHON_KEY_BYTES", key_bytes)
+    for shape, n in (("text", (1 << 20) + 3), ("random_copy", 1 << 20), ("text", 70001)):
+        x = S.gen_shape(shape, n)
+        P, B, b0 = oracle.forward(x)
+        sa, bwt, base = archon.forward(x)
+        assert (sa == P).all() and (bwt == B).all() and base == b0, (shape, n)
+        if shape == "text":
+            assert archon.stats()["radix_passes"] == int(key_bytes), archon.stats()["radix_passes"]
+
+
 def test_workspace_follows_the_block(archon, oracle):
     """the device workspace a forward call uses (archon_hip_stats.arena_bytes).  A block the streaming stage
     settles stays inside the first tier -- 26.2 bytes per input byte + 145 MB of fixed tables and slack (26.8 N at 256 MiB);
