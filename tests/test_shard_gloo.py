@@ -172,6 +172,38 @@ def test_gather_pipe_batched_exchange_one_rank():
     assert q.get(timeout=10) == (0, True)
 
 
+def test_gather_pipe_batched_fails_fast():
+    """the fail-fast rule in batch mode: the exchange of the first full batch fails in the helper thread -- the owner's next call raises,
+    nothing further is issued, a drain raises too, the helper is stopped all the same"""
+    sys.path.insert(0, os.path.join(ROOT, "dark-archon_amd"))
+    import archon_shard
+
+    class Boom(RuntimeError):
+        pass
+
+    class FakeDist:
+        calls = 0
+
+        def all_to_all_single(self, *a, **k):
+            FakeDist.calls += 1
+            raise Boom("exchange failed")
+
+    pipe = archon_shard.GatherPipe(FakeDist(), 0, 2, 16, torch.device("cpu"), via_host=True, rotate=True, batch=2)
+    for _ in range(2):
+        pipe.next_buffer()
+        pipe.submit()                   # the second one completes the batch: handed to the helper, which fails
+    with pytest.raises(Boom):
+        for _ in range(3):              # (buffers 2 and 3 are free; buffer 0 waits for the failed exchange)
+            pipe.next_buffer()
+            pipe.submit()
+    with pytest.raises(Boom):
+        pipe.submit()
+    assert FakeDist.calls == 1
+    with pytest.raises(Boom):
+        pipe.close()
+    assert pipe.queue is None
+
+
 def test_gather_pipe_batch_needs_rotating_roots():
     sys.path.insert(0, os.path.join(ROOT, "dark-archon_amd"))
     import archon_shard
