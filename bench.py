@@ -251,6 +251,7 @@ class Feeders:
         from concurrent.futures import ThreadPoolExecutor
         self.flight, self.dev_index, self.on_error = flight, dev_index, on_error
         self.tls = threading.local()
+        self.lock, self.bound = threading.Lock(), 0
         self.pool = ThreadPoolExecutor(flight)
 
     def _feed(self, t, count, body):
@@ -258,7 +259,11 @@ class Feeders:
         import pyarchon
         if not hasattr(self.tls, "stream"):
             torch.cuda.set_device(self.dev_index)
-            pyarchon.bind_context(t, self.dev_index)
+            # a context per THREAD, in the order the pool's threads first get work (the pool may hand part t to any of its threads,
+            # and to the same one twice when a part is empty): never two threads on one context, which would take turns at its mutex
+            with self.lock:
+                ctx, self.bound = self.bound, self.bound + 1
+            pyarchon.bind_context(ctx, self.dev_index)
             self.tls.stream = torch.cuda.Stream(device=torch.device("cuda", self.dev_index))
         try:
             with torch.cuda.stream(self.tls.stream):

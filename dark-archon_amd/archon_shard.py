@@ -149,6 +149,14 @@ class GatherPipe:
                     self.error = e
             ev.set()
 
+    def _complete(self, work):
+        """the collective behind `work` has finished when this returns -- for the HOST.  Over RCCL `work.wait()` only makes torch's
+        current stream wait; the sort that reuses the buffer runs on the library's own (non-blocking) stream, which that does not
+        order, so the host waits for the stream too (gloo's wait blocks the host by itself)."""
+        work.wait()
+        if not self.via_host and getattr(self.device, "type", "cpu") == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+
     def _wait_batch(self, need):
         """batch mode: step `need` (the last user of a buffer; < 0: none) has been exchanged -- first handed over (by whichever
         feeder completed its batch, or by a drain), then issued by the helper, then complete.  Several feeders may wait for one
@@ -168,7 +176,7 @@ class GatherPipe:
             raise self.error
         work = self.pending[g]
         if work is not None and not work.is_completed():
-            work.wait()
+            self._complete(work)
 
     def _wait(self, k):
         if self.issued[k] is not None:
@@ -179,7 +187,7 @@ class GatherPipe:
         if self.pending[k] is not None:
             # (a gather that has completed -- the usual case: it was issued two steps ago -- needs no wait on the stream)
             if not self.pending[k].is_completed():
-                self.pending[k].wait()
+                self._complete(self.pending[k])
             self.pending[k] = None
 
     def next_buffer(self):

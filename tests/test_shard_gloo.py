@@ -220,6 +220,46 @@ def test_gather_pipe_batch_needs_rotating_roots():
     assert archon_shard.GatherPipe(FakeDist(), 0, 1, 16, torch.device("cpu"), rotate=True, batch=1, threaded=False).batch == 1
 
 
+def test_gather_pipe_completes_for_the_host(monkeypatch):
+    """an exchange still running when its buffer is asked for again: the pipe waits on the work AND, over RCCL (device buffers, not
+    staged through the host), for torch's stream on the host -- the sort that reuses the buffer runs on the library's own stream,
+    which work.wait() does not order; a finished exchange is not waited for at all"""
+    sys.path.insert(0, os.path.join(ROOT, "dark-archon_amd"))
+    import archon_shard
+
+    class Work:
+        def __init__(self, done):
+            self.done, self.waits = done, 0
+
+        def is_completed(self):
+            return self.done
+
+        def wait(self):
+            self.waits += 1
+
+    class Stream:
+        syncs = 0
+
+        def synchronize(self):
+            Stream.syncs += 1
+
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: Stream())
+
+    class Dev:            # (what GatherPipe reads of a device; no GPU here)
+        type = "cuda"
+
+    for via_host, want in ((False, 1), (True, 0)):
+        Stream.syncs = 0
+        pipe = archon_shard.GatherPipe(None, 0, 1, 16, torch.device("cpu"))
+        pipe.device, pipe.via_host = Dev(), via_host
+        running, finished = Work(False), Work(True)
+        pipe.pending[0], pipe.pending[1] = running, finished
+        pipe._wait(0)
+        pipe._wait(1)
+        assert running.waits == 1 and finished.waits == 0 and Stream.syncs == want
+        assert pipe.pending[0] is None and pipe.pending[1] is None
+
+
 def test_gather_pipe_fails_fast():
     """the first exception of the helper thread ends the pipe -- no later gather is issued, and the owner's next
     call raises instead of leaving its peers in a collective nobody matches"""
