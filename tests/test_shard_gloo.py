@@ -159,6 +159,23 @@ def test_gather_pipe_batched_exchange(via_host, threaded, drain_every):
     assert res == {0: True, 1: True}
 
 
+@pytest.mark.parametrize("drain_every", [1, 100])
+def test_gather_pipe_batched_exchange_four_ranks(drain_every):
+    """the same at world 4 (the slot arithmetic with more than two ranks: step k in slot k mod 4 of batch buffer (k div 4) mod 2, its
+    payloads on rank k mod 4): 11 steps = two full batches and three quarters of one, every step checked on its root, and only the last"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + (os.getpid() % 1000) + drain_every % 29
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 4, port, True, q, False, True, 4, drain_every)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(4))
+    assert res == {0: True, 1: True, 2: True, 3: True}
+
+
 def test_gather_pipe_batched_exchange_one_rank():
     """bench.py --gather-batch -1 under torch.distributed.run with ONE rank: the batched exchange as the collective's self-test (the
     only form of it a one-GPU box can run over RCCL)"""
